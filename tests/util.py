@@ -1,0 +1,58 @@
+"""Shared helpers for the parity tests."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def hexes(v):
+    return [float(x).hex() for x in v]
+
+
+def kat_plane(kind, n):
+    """Same planes as tools/make_golden.py::kat_plane (guarded by plane_sha256 in golden.json)."""
+    from waverange_amd import synth
+    idx = np.arange(n, dtype=np.uint64)
+    h = synth.splitmix64(777, idx)
+    if kind == "uniform":
+        b = (h & np.uint64(0xFF)).astype(np.uint8)
+    elif kind == "skewed":
+        b = np.minimum((h & np.uint64(0xFF)), (h >> np.uint64(8)) & np.uint64(0xFF))
+        b = np.minimum(b, (h >> np.uint64(16)) & np.uint64(0xFF)).astype(np.uint8)
+    elif kind == "sparse":
+        b = np.zeros(n, dtype=np.uint8)
+        b[:: max(1, n // 37)] = 3
+    else:
+        raise ValueError(kind)
+    b = b.copy()
+    b[0], b[-1] = 0, 255
+    return b
+
+
+def check_enc_record(e, rec, what=""):
+    """Compare an encode result dict (oracle.loader format) with a golden.json record."""
+    assert float(e["tolabs"]).hex() == rec["tolabs"], what
+    assert float(e["midval"]).hex() == rec["midval"], what
+    assert float(e["halfspanval"]).hex() == rec["halfspanval"], what
+    assert e["wlev"] == rec["wlev"] and e["nlay"] == rec["nlay"], what
+    assert hexes(e["deps_vec"]) == rec["deps_vec"], what
+    assert hexes(e["minval_vec"]) == rec["minval_vec"], what
+    assert list(e["len_enc_vec"]) == rec["len_enc_vec"], what
+    assert e["ntot_enc"] == rec["ntot_enc"], what
+    assert sha(e["data"]) == rec["data_sha256"], what
