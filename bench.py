@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- WaveRange hot path on MI355X: encode + decode of a 3-D fp64 field that is
+resident in HBM (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; % HBM
+roofline; L-inf vs tol").
+
+One step = for each tolerance of the workload: encode (min/max, forward CDF-9/7, bit-plane
+quantizer on the GPU; planes D2H; rngcod13 range coder on host threads) followed by decode
+(range decoder on host threads; planes H2D; dequantise + inverse transform on the GPU) of one
+n^3 field per GPU.  value = field megabytes (10^6 B) round-tripped per second, whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7]
+
+N > 1: one process per GPU (torch.distributed / RCCL for the timing barrier only); every rank
+codes its own independent field (seed 12345 + rank): weak scaling, no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def box_elems(n, levels=4):
+    """sum over levels of the corner-box sizes: each level reads and writes its box once."""
+    tot, m = 0, n
+    for _ in range(levels):
+        tot += m ** 3
+        m = (m + 1) // 2
+    return tot
+
+
+def cpu_baseline(size, tols):
+    """The reference itself (oracle/_ref, kind "reference") or, if absent, the oracle port,
+    single thread, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import loader
+    from waverange_amd import synth
+    if loader.have_ref():
+        impl, kind = loader.Reference(), "reference"
+    else:
+        impl, kind = loader.Oracle(), "port"
+    f = synth.field(size, size, size, seed=12345)
+    fd = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    sys.stdout.flush()
+    os.dup2(devnull, 1)  # the reference prints progress lines from C++
+    try:
+        t0 = time.time()
+        for tol in tols:
+            enc = impl.encode(f, tol)
+            impl.decode(enc, f.shape)
+        dt = time.time() - t0
+    finally:
+        sys.stdout.flush()
+        os.dup2(fd, 1)
+        os.close(devnull)
+        os.close(fd)
+    mb = len(tols) * f.nbytes / 1e6
+    return {"value": round(mb / dt, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+            "sample": "%d^3 fp64 field of the same generator, tols %s, encode+decode, %.1f s"
+                      % (size, ",".join("%g" % t for t in tols), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--tols", type=str, default="1e-3,1e-7")
+    ap.add_argument("--cpu-size", type=int, default=320)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
+    tols = [float(t) for t in args.tols.split(",")]
+    n = args.size
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+    from waverange_amd import api
+    api.set_verbosity(0)
+    api.set_threads(args.threads)
+    if api.device_count() < 1:
+        raise SystemExit("bench.py: no GPU visible (libwaverange_amd has no CPU fallback)")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+
+    ctx = api.Context(local_rank)
+    shape = (n, n, n)
+    nelem = n ** 3
+    orig = ctx.alloc(nelem * 8)
+    work = ctx.alloc(nelem * 8)
+    ctx.synth_field(orig, n, n, n, 12345 + rank)
+    ctx.sync()
+    _, cap = api.setup_wr(n, n, n)
+    data = np.empty(cap, dtype=np.uint8)
+
+    stats = {t: {} for t in tols}
+    acc = {"fwd_ms": [], "inv_ms": [], "quant_ms": [], "dequant_ms": [], "enc_s": [], "dec_s": [],
+           "enc_rc_s": [], "dec_rc_s": [], "enc_gpu_s": [], "dec_gpu_s": []}
+
+    def step(record):
+        for tol in tols:
+            ctx.copy(work, orig, nelem * 8)
+            enc, te = ctx.encode(work, shape, tol, out=data)
+            td = ctx.decode(work, shape, enc)
+            if record:
+                acc["fwd_ms"].append(te["transform_ms"]); acc["inv_ms"].append(td["transform_ms"])
+                acc["quant_ms"].append(te["quant_ms"]); acc["dequant_ms"].append(td["quant_ms"])
+                acc["enc_s"].append(te["total"]); acc["dec_s"].append(td["total"])
+                acc["enc_rc_s"].append(te["rangecoder"]); acc["dec_rc_s"].append(td["rangecoder"])
+                acc["enc_gpu_s"].append(te["gpu"]); acc["dec_gpu_s"].append(td["gpu"])
+                stats[tol] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"]}
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # accuracy of the last reconstruction (tols[-1]) against the original, on the device
+    diff, amax = ctx.linf(orig, work, nelem)
+    linf_rel = diff / amax
+
+    mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
+    if rank == 0:
+        field_mb = nelem * 8 / 1e6
+        total_mb = world * args.steps * len(tols) * field_mb
+        alg_bytes = 16.0 * box_elems(n)             # per direction (18.28 B/elem at 2^k sizes)
+        fwd_ms, inv_ms = mean(acc["fwd_ms"]), mean(acc["inv_ms"])
+        t_ms = 0.5 * (fwd_ms + inv_ms)
+        achieved = alg_bytes / (t_ms * 1e-3) / 1e9
+        out = {
+            "metric": "encode+decode MB/s per GPU on 1024^3 fp64 (field resident in HBM; host range coder included)",
+            "value": round(total_mb / dt, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "single %d^3 fp64 field per GPU, tol=%s (BASELINE configs[2])"
+                                   % (n, " and ".join("%g" % t for t in tols)),
+                       "field_shards": world, "range_coder_threads": args.threads,
+                       "planes": {("%g" % t): stats[t] for t in tols}},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "3-D CDF-9/7 transform, 4 levels (mean of forward and inverse), all launches",
+                         "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3)},
+            "stages": {"encode_s": round(mean(acc["enc_s"]), 3), "decode_s": round(mean(acc["dec_s"]), 3),
+                       "encode_gpu_s": round(mean(acc["enc_gpu_s"]), 4), "decode_gpu_s": round(mean(acc["dec_gpu_s"]), 4),
+                       "encode_rangecoder_s": round(mean(acc["enc_rc_s"]), 3),
+                       "decode_rangecoder_s": round(mean(acc["dec_rc_s"]), 3),
+                       "quant_ms": round(mean(acc["quant_ms"]), 3), "dequant_ms": round(mean(acc["dequant_ms"]), 3),
+                       "device_only_MBps": round(2 * field_mb / max(1e-9, mean(acc["enc_gpu_s"]) + mean(acc["dec_gpu_s"])), 1)},
+            "accuracy": {"tol": tols[-1], "linf_rel": linf_rel},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+/*
+ * waverange_amd.h -- C ABI of libwaverange_amd.so: the MI355X (gfx950) implementation of
+ * WaveRange's encode/decode hot path (3-D CDF-9/7 transform + bit-plane quantizer on the
+ * GPU, rngcod13 range coder on the host).
+ *
+ * Part 1 are the drop-in entry points: the SAME unmangled symbols, argument order and
+ * meaning as the reference's libwaverange (src/core/wrappers.h:53,70,75,95,111,119).  The
+ * reference declares the scalar outputs as C++ references; at the SysV ABI level a
+ * reference is a pointer, so the declarations below are call-compatible with code compiled
+ * against the reference header.
+ *
+ * Part 2 is the device-resident API used by the tests, bench.py and multi-field callers:
+ * plain pointers and sizes only, HIP stream handles passed as void*.
+ *
+ * Error convention: Part 1 keeps the reference's "void + fatal" behaviour (a message on
+ * stderr and abort(); the reference throws through the extern "C" frame, wrappers.cpp:425,
+ * or exit(1)s, :170).  Part 2 functions return 0 on success and a negative code on error;
+ * wr_last_error() returns the message.  There is NO CPU fallback: without a usable GPU
+ * every compute entry point fails loudly.
+ */
+#ifndef WAVERANGE_AMD_H
+#define WAVERANGE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------- */
+/* Part 1: libwaverange drop-in symbols                                                 */
+/* ----------------------------------------------------------------------------------- */
+
+/* replaces setup_wr, reference src/core/wrappers.cpp:531-541 (wrappers.h:75) */
+void setup_wr(int nx, int ny, int nz, unsigned char *nlaymax, unsigned long *ntot_enc_max);
+
+/* replaces encoding_wrap, reference src/core/wrappers.cpp:228-452 (wrappers.h:53).
+ * fld_1d: host double[nx*ny*nz], x fastest.  data_enc: host buffer of ntot_enc_max bytes.
+ * Only the uniform cutoff (mx*my*mz == 1; what every reference CLI passes) is implemented
+ * on the GPU; mx*my*mz > 1 is a fatal error.  Unlike the reference, fld_1d is left
+ * untouched unless WR_WRITEBACK_RESIDUAL=1 is set in the environment. */
+void encoding_wrap(int nx, int ny, int nz, double *fld_1d, int wtflag, int mx, int my, int mz,
+                   double *cutoffvec, double *tolabs, double *midval, double *halfspanval,
+                   unsigned char *wlev, unsigned char *nlay, unsigned long *ntot_enc,
+                   double *deps_vec, double *minval_vec, unsigned long *len_enc_vec,
+                   unsigned char *data_enc);
+
+/* replaces decoding_wrap, reference src/core/wrappers.cpp:456-527 (wrappers.h:70) */
+void decoding_wrap(int nx, int ny, int nz, double *fld_1d, double *tolabs, double *midval,
+                   double *halfspanval, unsigned char *wlev, unsigned char *nlay,
+                   unsigned long *ntot_enc, double *deps_vec, double *minval_vec,
+                   unsigned long *len_enc_vec, unsigned char *data_enc);
+
+/* Fortran shims, reference src/core/wrappers.cpp:545-594 (wrappers.h:95,111,119) */
+void setup_wr_f(int *nx, int *ny, int *nz, int *nlaymax, long *ntot_enc_max);
+void encoding_wrap_f(int *nx, int *ny, int *nz, double *fld, int *wtflag, double *tolrel,
+                     double *tolabs, double *midval, double *halfspanval, unsigned char *wlev,
+                     unsigned char *nlay, long *ntot_enc, double *deps_vec, double *minval_vec,
+                     long *len_enc_vec, unsigned char *data_enc);
+void decoding_wrap_f(int *nx, int *ny, int *nz, double *fld, double *midval, double *halfspanval,
+                     unsigned char *wlev, unsigned char *nlay, long *ntot_enc, double *deps_vec,
+                     double *minval_vec, long *len_enc_vec, unsigned char *data_enc);
+
+/* replaces waveletcdf97_3d, reference src/waveletcdf97_3d/waveletcdf97_3d.c:38 (exported by
+ * the reference's .so; host buffer, in place; lvl>0 forward, lvl<0 inverse) */
+void waveletcdf97_3d(int n1, int n2, int n3, int lvl, double *x);
+
+/* ----------------------------------------------------------------------------------- */
+/* Part 2: device-resident API                                                          */
+/* ----------------------------------------------------------------------------------- */
+
+#define WR_NLAYMAX 8 /* reference src/core/defs.h:38 */
+#define WR_OK 0
+#define WR_ERR_ARG (-1)
+#define WR_ERR_HIP (-2)
+#define WR_ERR_UNSUPPORTED (-3)
+#define WR_ERR_STREAM (-4)
+#define WR_ERR_OVERFLOW (-5)
+
+typedef struct wr_ctx wr_ctx;
+
+/* outputs of one encode = the header record of a field (reference .wrh fields) */
+typedef struct wr_enc_info {
+    double tolabs, midval, halfspanval;
+    unsigned char wlev, nlay;
+    unsigned long ntot_enc;
+    double deps_vec[WR_NLAYMAX];
+    double minval_vec[WR_NLAYMAX];
+    unsigned long len_enc_vec[WR_NLAYMAX];
+} wr_enc_info;
+
+/* per-call stage timings in seconds (host wall clock around the stages) */
+typedef struct wr_timings {
+    double total;      /* whole call */
+    double gpu;        /* device kernels: min/max + transform + quantizer or dequant + inverse */
+    double transfer;   /* plane D2H / H2D not hidden behind the range coder */
+    double rangecoder; /* host range coder, wall time of the slowest plane thread */
+    /* HIP-event durations on the context's stream, milliseconds */
+    float transform_ms; /* all launches of the forward or inverse transform */
+    float quant_ms;     /* all quantizer-plane (or the dequantise-accumulate) launches */
+    float minmax_ms;    /* stand-alone min/max reductions */
+} wr_timings;
+
+const char *wr_last_error(void);
+int wr_device_count(void);
+/* 0 = silent, 1 = the reference's progress lines on stdout (default; WR_QUIET=1 silences) */
+void wr_set_verbosity(int level);
+/* number of host range-coder threads (default: one per plane, WR_NLAYMAX max) */
+void wr_set_threads(int nthreads);
+
+/* One context per (device, stream owner).  Work space (scratch field, plane buffers, pinned
+ * staging) is grown on demand and kept.  stream == NULL makes the context create its own. */
+int wr_ctx_create(wr_ctx **ctx, int device, void *hip_stream);
+void wr_ctx_destroy(wr_ctx *ctx);
+int wr_ctx_sync(wr_ctx *ctx);
+/* keep_residual != 0: also apply the residual update on the last plane, so that the device
+ * field ends up bit-identical to what the reference leaves in fld_1d (wrappers.cpp:397-398) */
+void wr_ctx_set_keep_residual(wr_ctx *ctx, int keep_residual);
+
+/* device memory helpers (thin hipMalloc/hipMemcpy wrappers so callers need no HIP headers) */
+int wr_dev_alloc(wr_ctx *ctx, void **ptr, size_t bytes);
+int wr_dev_free(wr_ctx *ctx, void *ptr);
+int wr_dev_upload(wr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int wr_dev_download(wr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+int wr_dev_copy(wr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* async, ctx stream */
+/* max|a-b| and max|a| over n doubles (accuracy check of a reconstruction, "L-inf vs tol") */
+int wr_dev_linf(wr_ctx *ctx, const double *d_a, const double *d_b, size_t n, double *max_abs_diff,
+                double *max_abs_a);
+
+/* --- stage-level entry points on device pointers (d_ prefix = device memory, 16-B aligned) */
+/* transform in place: a1/a2 of SURVEY.md 8a */
+int wr_dev_transform(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int lvl);
+/* min/max with the reference's scan semantics incl. the sign of a zero minimum: a4/a5 */
+int wr_dev_minmax(wr_ctx *ctx, const double *d_x, size_t n, double *mn, double *mx);
+/* one quantizer plane + residual update; next_min/next_max = extrema of the new residual */
+int wr_dev_quantize_plane(wr_ctx *ctx, double *d_x, size_t n, double deps, double minval,
+                          unsigned char *d_q, double *next_min, double *next_max);
+/* acc = sum over planes of (q*deps + minval), planes are nlay device arrays of n bytes */
+int wr_dev_dequant_accum(wr_ctx *ctx, double *d_acc, size_t n, int nlay,
+                         const unsigned char *const *d_planes, const double *deps,
+                         const double *minval);
+/* synthetic field generator (waverange_amd/synth.py) straight into device memory */
+int wr_dev_synth_field(wr_ctx *ctx, double *d_out, int nx, int ny, int nz,
+                       unsigned long long seed);
+
+/* --- device-only part of the codec (no range coder): transform + all quantizer planes.
+ * d_fld is consumed (holds the residual afterwards).  d_planes receives nlay planes at a
+ * pitch of wr_plane_pitch(n) bytes.  Fills tolabs/midval/halfspanval/wlev/nlay/deps/minval. */
+size_t wr_plane_pitch(size_t n);
+int wr_dev_encode_planes(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtflag,
+                         double tolrel, unsigned char *d_planes, wr_enc_info *info);
+int wr_dev_decode_planes(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz,
+                         const unsigned char *d_planes, const wr_enc_info *info);
+
+/* --- whole hot path with the field resident in HBM: encode -> host byte stream, and back.
+ * data_enc: host buffer of at least setup_wr()'s ntot_enc_max bytes (cap is checked). */
+int wr_encode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtflag,
+                     double tolrel, wr_enc_info *info, unsigned char *data_enc, size_t cap,
+                     wr_timings *tm);
+int wr_decode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz,
+                     const wr_enc_info *info, const unsigned char *data_enc, wr_timings *tm);
+
+/* --- host range coder alone (one plane stream), rows a6/a7/a10 of SURVEY.md 8a */
+size_t wr_range_encode_bound(size_t n);
+size_t wr_range_encode(const unsigned char *sym, size_t n, unsigned char *out);
+size_t wr_range_decode(const unsigned char *in, size_t len, unsigned char *sym, size_t n);
+
+/* --- measurement hook for bench.py: runs `reps` forward (lvl>0) or inverse transforms of an
+ * nx*ny*nz field back to back on the context's stream and returns the average duration of
+ * one transform in milliseconds measured with HIP events on that stream. */
+int wr_bench_transform(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int lvl, int reps,
+                       double *ms_per_transform);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

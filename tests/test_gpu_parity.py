@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, bit for bit.
+Run on the GPU box: python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from util import bits_equal, check_enc_record, sha
+from waverange_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 64, 64), (13, 9, 7), (37, 21, 13), (33, 5, 1), (2, 2, 2), (3, 3, 3), (17, 1, 1),
+          (9, 1, 40), (1, 4, 1), (100, 3, 2), (130, 70, 34), (256, 8, 4), (1030, 6, 5)]
+
+
+@pytest.fixture(scope="module")
+def api():
+    from waverange_amd import api as a
+    a.set_verbosity(0)
+    return a
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_transform_bit_exact(ctx, oracle, shape):
+    nx, ny, nz = shape
+    f = synth.field(nx, ny, nz, seed=nx * 131 + ny)
+    buf = ctx.to_device(f)
+    for lvl in (4, 1, 2):
+        buf.upload(f)
+        ctx.transform(buf, f.shape, lvl)
+        ctx.sync()
+        fw = buf.download(np.float64, f.size)
+        want = oracle.cdf97_3d(f, lvl)
+        assert bits_equal(fw, want), ("fwd", shape, lvl)
+        ctx.transform(buf, f.shape, -lvl)
+        ctx.sync()
+        assert bits_equal(buf.download(np.float64, f.size), oracle.cdf97_3d(want, -lvl)), ("inv", shape, lvl)
+    buf.free()
+
+
+def test_transform_golden(ctx, golden):
+    for name in ("64x64x64", "37x21x13", "5x1x33", "2x3x1", "130x70x34"):
+        nx, ny, nz = (int(v) for v in name.split("x"))
+        g = golden["G2"][name]
+        f = synth.field(nx, ny, nz, seed=g["seed"])
+        buf = ctx.to_device(f)
+        ctx.transform(buf, f.shape, 4)
+        ctx.sync()
+        assert sha(buf.download(np.float64, f.size)) == g["fwd_sha256"], name
+        ctx.transform(buf, f.shape, -4)
+        ctx.sync()
+        assert sha(buf.download(np.float64, f.size)) == g["inv_sha256"], name
+        buf.free()
+
+
+def test_synth_field_device_matches_numpy(ctx):
+    for (nx, ny, nz, seed) in ((64, 64, 64, 12345), (37, 21, 13, 7), (128, 32, 16, 99)):
+        buf = ctx.alloc(nx * ny * nz * 8)
+        ctx.synth_field(buf, nx, ny, nz, seed)
+        ctx.sync()
+        assert bits_equal(buf.download(np.float64, nx * ny * nz), synth.field(nx, ny, nz, seed=seed))
+        buf.free()
+
+
+def test_minmax_and_zero_sign(ctx, oracle):
+    rs = np.random.RandomState(0)
+    for n in (1, 2, 3, 1000, 65537, 1 << 20):
+        x = rs.standard_normal(n)
+        buf = ctx.to_device(x)
+        assert ctx.minmax(buf, n) == oracle.minmax(x)
+        buf.free()
+    # minimum is a zero: the sign of the LAST zero in memory order wins (reference fmin scan)
+    for zeros in ([0.0, -0.0], [-0.0, 0.0], [-0.0, 0.0, -0.0]):
+        x = np.abs(rs.standard_normal(5000)) + 1.0
+        pos = sorted(rs.choice(5000, len(zeros), replace=False))
+        for p, z in zip(pos, zeros):
+            x[p] = z
+        buf = ctx.to_device(x)
+        mn, mx = ctx.minmax(buf, x.size)
+        omn, omx = oracle.minmax(x)
+        assert mn == 0 and np.signbit(mn) == np.signbit(omn) and mx == omx
+        buf.free()
+    # NaNs are skipped, as the reference's fmin/fmax do
+    x = rs.standard_normal(1000)
+    x[::17] = np.nan
+    buf = ctx.to_device(x)
+    assert ctx.minmax(buf, x.size) == oracle.minmax(x)
+    buf.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 4096, 100003])
+def test_quantize_plane_bit_exact(ctx, oracle, n):
+    rs = np.random.RandomState(n)
+    x = rs.standard_normal(n) * 3.0
+    lo, hi = oracle.minmax(x)
+    deps = (hi - lo) / 255.0 if n > 1 else 0.5
+    q_want, r_want = oracle.quantize_plane(x, deps, lo)
+    buf = ctx.to_device(x)
+    qbuf = ctx.alloc(n + 16)
+    nlo, nhi = ctx.quantize_plane(buf, n, deps, lo, qbuf)
+    assert np.array_equal(qbuf.download(np.uint8, n), q_want)
+    assert bits_equal(buf.download(np.float64, n), r_want)
+    assert (nlo, nhi) == oracle.minmax(r_want)
+    buf.free()
+    qbuf.free()
+
+
+def test_dequant_accum_bit_exact(ctx, oracle):
+    rs = np.random.RandomState(2)
+    for n in (1, 5, 4096, 100003):
+        for nlay in (1, 3, 8):
+            planes = [rs.randint(0, 256, n).astype(np.uint8) for _ in range(nlay)]
+            deps = [10.0 ** (-2 * i) * 0.37 for i in range(nlay)]
+            mins = [-(10.0 ** (-2 * i)) * 1.1 for i in range(nlay)]
+            want = np.zeros(n)
+            for q, d, m in zip(planes, deps, mins):
+                want = oracle.dequant_accum(want, q, d, m)
+            bufs = [ctx.to_device(q) for q in planes]
+            acc = ctx.alloc(n * 8)
+            ctx.dequant_accum(acc, n, bufs, deps, mins)
+            ctx.sync()
+            assert bits_equal(acc.download(np.float64, n), want)
+            for b in bufs + [acc]:
+                b.free()
+
+
+def _device_encode(ctx, f, tol, wtflag=1):
+    buf = ctx.to_device(f)
+    ctx.set_keep_residual(True)
+    enc, tm = ctx.encode(buf, f.shape, tol, wtflag=wtflag)
+    resid = buf.download(np.float64, f.size)
+    enc["data"] = enc["data"].copy()
+    dec_buf = ctx.alloc(f.nbytes)
+    ctx.decode(dec_buf, f.shape, enc)
+    rec = dec_buf.download(np.float64, f.size).reshape(f.shape)
+    buf.free()
+    dec_buf.free()
+    ctx.set_keep_residual(False)
+    return enc, resid, rec
+
+
+@pytest.mark.parametrize("tol", ["1e-3", "1e-5", "1e-7", "1e-16"])
+def test_codec_golden_64(ctx, golden, tol):
+    """Config 1 shape (64^3 fp64): every output of encoding_wrap, the coded bytes, the
+    residual left in the field and the reconstruction equal the reference's."""
+    f = synth.field(64, 64, 64, seed=12345)
+    enc, resid, rec = _device_encode(ctx, f, float(tol))
+    g = golden["G1"][tol]
+    check_enc_record(enc, g, tol)
+    assert sha(resid) == g["residual_sha256"]
+    assert sha(rec) == g["decoded_sha256"]
+    s = enc["data"]
+    off = 0
+    for ln in enc["len_enc_vec"]:   # structural anchors: first byte 0, 24-bit length trailer
+        assert s[off] == 0
+        assert (int(s[off + ln - 3]) << 16 | int(s[off + ln - 2]) << 8 | int(s[off + ln - 1])) == ln % (1 << 24)
+        off += ln
+
+
+@pytest.mark.parametrize("shape,tol,wtflag", [((37, 21, 13), 1e-6, 1), ((64, 64, 8), 1e-4, 0),
+                                              ((60, 50, 40), 1e-10, 1), ((5, 1, 33), 1e-3, 1),
+                                              ((128, 128, 128), 1e-5, 1), ((2, 1, 1), 1e-3, 1)])
+def test_codec_vs_oracle(ctx, oracle, shape, tol, wtflag):
+    nx, ny, nz = shape
+    f = synth.field(nx, ny, nz, seed=4242)
+    enc, resid, rec = _device_encode(ctx, f, tol, wtflag)
+    want = oracle.encode(f, tol, wtflag=wtflag)
+    for k in ("tolabs", "midval", "halfspanval", "wlev", "nlay", "ntot_enc", "len_enc_vec"):
+        assert enc[k] == want[k], k
+    assert bits_equal(enc["deps_vec"], want["deps_vec"]) and bits_equal(enc["minval_vec"], want["minval_vec"])
+    assert np.array_equal(enc["data"], want["data"])
+    assert bits_equal(resid, want["residual"])
+    assert bits_equal(rec, oracle.decode(want, f.shape))
+
+
+def test_trivial_field(ctx, golden):
+    g = golden["G4"]
+    f = np.full((4, 5, 6), g["value"])
+    enc, _, rec = _device_encode(ctx, f, 1e-6)
+    assert (enc["ntot_enc"], enc["nlay"], enc["wlev"]) == (g["ntot_enc"], g["nlay"], g["wlev"])
+    assert float(enc["midval"]).hex() == g["midval"] and float(enc["halfspanval"]).hex() == g["halfspanval"]
+    assert np.array_equal(rec, f)
+
+
+def test_device_only_planes(ctx, api, oracle):
+    """wr_dev_encode_planes / wr_dev_decode_planes (no range coder): planes equal the
+    oracle's quantized planes, reconstruction equals the oracle's."""
+    f = synth.field(48, 40, 24, seed=3)
+    n = f.size
+    want = oracle.encode(f, 1e-6)
+    pitch = api.lib().wr_plane_pitch(n)
+    buf = ctx.to_device(f)
+    planes = ctx.alloc(pitch * 8)
+    info = ctx.encode_planes(buf, f.shape, 1e-6, planes)
+    assert info.nlay == want["nlay"]
+    off = 0
+    for l in range(info.nlay):
+        q = planes.download(np.uint8, n, offset=l * pitch)
+        stream = want["data"][off:off + want["len_enc_vec"][l]]
+        off += want["len_enc_vec"][l]
+        back, got = oracle.range_decode(stream, n)
+        assert got == n and np.array_equal(q, back), l
+    out = ctx.alloc(f.nbytes)
+    ctx.decode_planes(out, f.shape, planes, info)
+    assert bits_equal(out.download(np.float64, n), oracle.decode(want, f.shape))
+    for b in (buf, planes, out):
+        b.free()
+
+
+def test_host_pointer_drop_in_api(api, golden):
+    """encoding_wrap / decoding_wrap with host buffers (the libwaverange drop-in symbols)."""
+    f = synth.field(64, 64, 64, seed=12345)
+    enc = api.encoding_wrap(f, 1e-7)
+    g = golden["G1"]["1e-7"]
+    check_enc_record(enc, g)
+    assert sha(api.decoding_wrap(enc, f.shape)) == g["decoded_sha256"]
+    g2 = golden["G2"]["64x64x64"]
+    assert sha(api.waveletcdf97_3d(f, 4)) == g2["fwd_sha256"]
+
+
+def test_large_roundtrip_properties(ctx, oracle):
+    """256^3 against the oracle bit for bit; 512^3 (config 2: tol 1e-5) through size-independent
+    properties: stream anchors, decode(encode(f)) within the tolerance band the reference
+    itself achieves, and transform round trip at round-off level."""
+    f = synth.field(256, 256, 256, seed=12345)
+    buf = ctx.to_device(f)
+    enc, _ = ctx.encode(buf, f.shape, 1e-5)
+    enc["data"] = enc["data"].copy()
+    want = oracle.encode(f, 1e-5)
+    assert np.array_equal(enc["data"], want["data"]) and enc["len_enc_vec"] == want["len_enc_vec"]
+    ctx.decode(buf, f.shape, enc)
+    assert bits_equal(buf.download(np.float64, f.size), oracle.decode(want, f.shape))
+    buf.free()
+
+    n = 512
+    buf = ctx.alloc(n ** 3 * 8)
+    ctx.synth_field(buf, n, n, n, 12345)
+    ctx.sync()
+    orig = buf.download(np.float64, n ** 3)
+    ctx.transform(buf, (n, n, n), 4)
+    ctx.transform(buf, (n, n, n), -4)
+    ctx.sync()
+    back = buf.download(np.float64, n ** 3)
+    assert np.abs(back - orig).max() < 1e-12 * np.abs(orig).max()
+    buf.upload(orig)
+    enc, tm = ctx.encode(buf, (n, n, n), 1e-5)
+    assert 1 <= enc["nlay"] <= 8 and sum(enc["len_enc_vec"]) == enc["ntot_enc"]
+    off = 0
+    for ln in enc["len_enc_vec"]:
+        assert enc["data"][off] == 0
+        off += ln
+    ctx.decode(buf, (n, n, n), enc)
+    rec = buf.download(np.float64, n ** 3)
+    linf = np.abs(rec - orig).max() / np.abs(orig).max()
+    assert linf < 1.05e-5, linf     # the reference itself may exceed tol by ~1 %
+    buf.free()

@@ -1,0 +1,52 @@
+// wr_kernels.h -- launchers for the gfx950 kernels of the WaveRange hot path.
+//
+// Everything here works on DEVICE pointers and enqueues on the given HIP stream; nothing
+// synchronises.  Canonical arithmetic is strict IEEE double without FMA contraction
+// (the library is compiled with -ffp-contract=off; see DESIGN.md "Arithmetic").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace wrk {
+
+// ---- 3-D CDF-9/7 lifting transform (reference src/waveletcdf97_3d/waveletcdf97_3d.c:38-468)
+// In place on `fld` (nx*ny*nz doubles, x fastest); `scratch` is a second buffer of the same
+// size.  lvl > 0 forward, lvl < 0 inverse, 0 identity.
+void transform(double* fld, double* scratch, int nx, int ny, int nz, int lvl, hipStream_t st);
+
+// ---- reductions (reference src/core/wrappers.cpp:244-250, 308-314)
+// partial[] needs 2*minmax_partials() doubles; result (min, max) lands in result[0..1] (device).
+int minmax_partials();
+void minmax(const double* x, size_t n, double* partial, double* result, hipStream_t st);
+// sign bit of the LAST element equal to zero (the reference's fmin scan keeps the last of
+// equal values): out[0] = index+1 of that element (0 if none).  Rare path (min == 0 only).
+void last_zero_index(const double* x, size_t n, unsigned long long* out, hipStream_t st);
+
+// ---- quantizer plane (wrappers.cpp:339-340, 384-398) fused with the min/max of the residual
+// q[j] = (uchar)(aopt*x[j] + bopt); if write_resid: x[j] -= q[j]*deps + minval and
+// result[0..1] = min/max of the new residual.
+void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval,
+                    uint8_t* q, bool write_resid, double* partial, double* result, hipStream_t st);
+
+// ---- decoder accumulation (wrappers.cpp:480, 513-514): acc = 0; acc += q_l*deps_l + min_l, l in order
+struct DequantParams {
+    const uint8_t* q[8];
+    double deps[8];
+    double minval[8];
+    int nlay;
+};
+void dequant_accum(double* acc, size_t n, const DequantParams& p, hipStream_t st);
+
+// ---- helpers
+// result[0] = max|a-b|, result[1] = max|a|  (partial: 2*minmax_partials() doubles)
+void linf_diff(const double* a, const double* b, size_t n, double* partial, double* result, hipStream_t st);
+void fill(double* x, size_t n, double v, hipStream_t st);
+// synthetic field of waverange_amd/synth.py, planes z0..z1-1, written at out[0..]
+void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, int z0, int z1,
+                 hipStream_t st);
+// per-60000-symbol-block byte histograms of a plane (feeds the host range coder's model):
+// hist[b*256 + v] = count of value v in block b (uint16, block size < 65536)
+void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st);
+
+}  // namespace wrk

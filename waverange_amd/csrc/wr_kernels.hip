@@ -1,0 +1,564 @@
+// wr_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the WaveRange hot path.
+//
+// What is here (round 1):
+//   k_line_x      x-axis lifting of whole lines staged in LDS (in place)
+//   k_stream      y-/z-axis lifting as a streaming register pipeline, one thread per x
+//                 (coalesced along x), out of place (ping-pong)
+//   k_minmax*     min/max reductions
+//   k_quant       bit-plane quantizer fused with the residual update and its min/max
+//   k_dequant     fused multi-plane dequantise-accumulate
+//   k_synth       synthetic field generator, k_hist per-block histograms
+//
+// Arithmetic contract: every floating-point expression below is written exactly as the
+// reference evaluates it (one rounding per * and per +); the translation unit is compiled
+// with -ffp-contract=off and additionally pins it with the pragma below.  No MFMA: this is
+// a 9-tap stencil + byte packing, HBM-bound.
+#include "wr_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace wrk {
+
+// ---- constants: reference src/waveletcdf97_3d/waveletcdf97_3d.c:41-45,55-58 (values as
+// hex doubles from SURVEY.md A.1; 2*c is exact so (c*2)*v is written with a folded constant)
+#define WR_ALPHA (-0x1.960ce676401a2p+0)
+#define WR_BETA (-0x1.b2035c9357a96p-5)
+#define WR_GAMMA (0x1.c40ceba5738p-1)
+#define WR_DELTA (0x1.c626a904721eep-2)
+#define WR_ZETA (0x1.264c795071464p+0)
+#define WR_IZETA (0x1.bd5edf975ce17p-1)
+#define WR_EXT0 (-0x1.4f43b88aa31b3p-3)
+#define WR_EXT1 (0x1.a6be82e3706b1p-4)
+#define WR_EXT2 (0x1.0f7c8ee31b63bp+0)
+
+static_assert(WR_ALPHA == -1.5861343420693648 && WR_BETA == -0.0529801185718856 &&
+                  WR_GAMMA == 0.8829110755411875 && WR_DELTA == 0.4435068520511142 &&
+                  WR_ZETA == 1.1496043988602418,
+              "lifting constants");
+static_assert(WR_IZETA == 1.0 / 1.1496043988602418, "1/zeta is the compile-time quotient");
+static_assert(WR_EXT0 == -2 * WR_ALPHA * WR_BETA * WR_GAMMA / (1 + 2 * WR_BETA * WR_GAMMA), "ext0");
+static_assert(WR_EXT1 == -2 * WR_BETA * WR_GAMMA / (1 + 2 * WR_BETA * WR_GAMMA), "ext1");
+static_assert(WR_EXT2 == -2 * (WR_ALPHA + WR_GAMMA + 3 * WR_ALPHA * WR_BETA * WR_GAMMA) /
+                             (1 + 2 * WR_BETA * WR_GAMMA),
+              "ext2");
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// =====================================================================================
+// x-axis pass: R whole lines per workgroup staged in LDS, four lifting sweeps with a
+// workgroup barrier between them, in place.  (waveletcdf97_3d.c:82-142 fwd, :410-465 inv)
+// =====================================================================================
+template <bool INV>
+__global__ __launch_bounds__(256) void k_line_x(double* __restrict__ X, int n, int n2, int n3,
+                                                size_t sy, size_t sz, int R)
+{
+    extern __shared__ double lds[];
+    const int m = (n + 1) >> 1;  // low-pass length
+    const int mp = m + 1;        // row pitch (+1: keeps S/D rows off the same bank phase)
+    double* S = lds;
+    double* D = lds + (size_t)R * mp;
+    const long long nlines = (long long)n2 * n3;
+    const long long line0 = (long long)blockIdx.x * R;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const bool odd = n & 1;
+
+    // ---- load (coalesced over the line), de-interleave (fwd) or scale (inv)
+    for (int e = tid; e < R * n; e += nt) {
+        int r = e / n, j = e - r * n;
+        long long line = line0 + r;
+        if (line >= nlines) break;
+        size_t base = (size_t)(line % n2) * sy + (size_t)(line / n2) * sz;
+        double v = X[base + j];
+        if (!INV) {
+            if (j & 1) D[r * mp + (j >> 1)] = v; else S[r * mp + (j >> 1)] = v;
+        } else {
+            if (j < m) S[r * mp + j] = v * WR_IZETA; else D[r * mp + (j - m)] = v * WR_ZETA;
+        }
+    }
+    __syncthreads();
+    if (odd) {
+        // fwd: synthesise the missing last odd sample (:109); inv: it is zero (:314)
+        for (int r = tid; r < R; r += nt) {
+            double* s = S + r * mp; double* d = D + r * mp;
+            if (!INV) d[m - 1] = (s[m - 2] * WR_EXT0 + d[m - 2] * WR_EXT1) + s[m - 1] * WR_EXT2;
+            else d[m - 1] = 0.0;
+        }
+        __syncthreads();
+    }
+    const int np = R * m;
+    if (!INV) {
+        for (int e = tid; e < np; e += nt) {  // d += alpha (s[i+1]+s[i])
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            d[i] = (i < m - 1) ? d[i] + WR_ALPHA * (s[i + 1] + s[i]) : d[i] + (WR_ALPHA * 2) * s[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < np; e += nt) {  // s += beta (d[i]+d[i-1])
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            s[i] = (i > 0) ? s[i] + WR_BETA * (d[i] + d[i - 1]) : s[i] + (WR_BETA * 2) * d[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < np; e += nt) {
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            d[i] = (i < m - 1) ? d[i] + WR_GAMMA * (s[i + 1] + s[i]) : d[i] + (WR_GAMMA * 2) * s[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < np; e += nt) {
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            s[i] = (i > 0) ? s[i] + WR_DELTA * (d[i] + d[i - 1]) : s[i] + (WR_DELTA * 2) * d[i];
+        }
+    } else {
+        for (int e = tid; e < np; e += nt) {
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            s[i] = (i > 0) ? s[i] - WR_DELTA * (d[i] + d[i - 1]) : s[i] - (WR_DELTA * 2) * d[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < np; e += nt) {
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            d[i] = (i < m - 1) ? d[i] - WR_GAMMA * (s[i + 1] + s[i]) : d[i] - (WR_GAMMA * 2) * s[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < np; e += nt) {
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            s[i] = (i > 0) ? s[i] - WR_BETA * (d[i] + d[i - 1]) : s[i] - (WR_BETA * 2) * d[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < np; e += nt) {
+            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
+            d[i] = (i < m - 1) ? d[i] - WR_ALPHA * (s[i + 1] + s[i]) : d[i] - (WR_ALPHA * 2) * s[i];
+        }
+    }
+    __syncthreads();
+    // ---- store (coalesced): fwd = [low | high] with scaling, inv = interleave
+    for (int e = tid; e < R * n; e += nt) {
+        int r = e / n, j = e - r * n;
+        long long line = line0 + r;
+        if (line >= nlines) break;
+        size_t base = (size_t)(line % n2) * sy + (size_t)(line / n2) * sz;
+        double v;
+        if (!INV) v = (j < m) ? S[r * mp + j] * WR_ZETA : D[r * mp + (j - m)] * WR_IZETA;
+        else v = (j & 1) ? D[r * mp + (j >> 1)] : S[r * mp + (j >> 1)];
+        X[base + j] = v;
+    }
+}
+
+// =====================================================================================
+// y-/z-axis pass: one thread per x (coalesced), marching along the axis with the four
+// lifting stages held as a register pipeline ("streaming lifting"); src -> dst.
+//   forward  reads rows 2t, 2t+1          writes rows j (low) and m+j (high), j = t-2
+//   inverse  reads rows t (low), q+t (high) writes rows 2j, 2j+1
+// (waveletcdf97_3d.c:146-270 fwd, :292-406 inv)
+// =====================================================================================
+template <bool INV>
+__global__ __launch_bounds__(64) void k_stream(const double* __restrict__ src, double* __restrict__ dst,
+                                               int n, size_t sa, int n1, size_t sb)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n1) return;
+    const size_t base = (size_t)x + (size_t)blockIdx.y * sb;
+    const double* in = src + base;
+    double* out = dst + base;
+    const int m = (n + 1) >> 1;
+
+    if (!INV) {
+        double sr1 = 0, dr1 = 0, p1 = 0, q1 = 0, p2 = 0;
+        double s0 = in[0];
+        double d0 = (1 < n) ? in[sa] : 0.0;  // n >= 2 always (caller skips shorter axes)
+        for (int t = 0; t <= m + 1; t++) {
+            // prefetch pair t+1 while pair t is being consumed
+            double s_nx = 0, d_nx = 0;
+            if (t + 1 < m) {
+                s_nx = in[(size_t)(2 * t + 2) * sa];
+                if (2 * t + 3 < n) d_nx = in[(size_t)(2 * t + 3) * sa];
+            }
+            if (t == m - 1 && (n & 1)) d0 = (sr1 * WR_EXT0 + dr1 * WR_EXT1) + s0 * WR_EXT2;
+            double D1 = 0, S1 = 0;
+            if (t >= 1 && t <= m) {
+                const int j = t - 1;
+                D1 = (j < m - 1) ? dr1 + WR_ALPHA * (s0 + sr1) : dr1 + (WR_ALPHA * 2) * sr1;
+                S1 = (j > 0) ? sr1 + WR_BETA * (D1 + p1) : sr1 + (WR_BETA * 2) * D1;
+            }
+            if (t >= 2) {
+                const int j = t - 2;
+                double D2 = (j < m - 1) ? p1 + WR_GAMMA * (S1 + q1) : p1 + (WR_GAMMA * 2) * q1;
+                double S2 = (j > 0) ? q1 + WR_DELTA * (D2 + p2) : q1 + (WR_DELTA * 2) * D2;
+                out[(size_t)j * sa] = S2 * WR_ZETA;
+                if (2 * j + 1 < n) out[(size_t)(m + j) * sa] = D2 * WR_IZETA;
+                p2 = D2;
+            }
+            p1 = D1; q1 = S1; sr1 = s0; dr1 = d0;
+            s0 = s_nx; d0 = d_nx;
+        }
+    } else {
+        const int q = m;          // number of low-pass rows
+        const int nh = n - q;     // number of high-pass rows
+        double dprev = 0, s1prev = 0, d1prev = 0, s2prev = 0;
+        double lo = in[0];
+        double hi = (0 < nh) ? in[(size_t)q * sa] : 0.0;
+        for (int t = 0; t <= q + 1; t++) {
+            double lo_nx = 0, hi_nx = 0;
+            if (t + 1 < q) {
+                lo_nx = in[(size_t)(t + 1) * sa];
+                if (t + 1 < nh) hi_nx = in[(size_t)(q + t + 1) * sa];
+            }
+            double d0 = 0, S1 = 0, D1 = 0, S2 = 0;
+            if (t < q) {
+                double s0 = lo * WR_IZETA;
+                d0 = (t < nh) ? hi * WR_ZETA : 0.0;
+                S1 = (t > 0) ? s0 - WR_DELTA * (d0 + dprev) : s0 - (WR_DELTA * 2) * d0;
+            }
+            if (t >= 1 && t <= q) {
+                const int j = t - 1;
+                D1 = (j < q - 1) ? dprev - WR_GAMMA * (S1 + s1prev) : dprev - (WR_GAMMA * 2) * s1prev;
+                S2 = (j > 0) ? s1prev - WR_BETA * (D1 + d1prev) : s1prev - (WR_BETA * 2) * D1;
+            }
+            if (t >= 2) {
+                const int j = t - 2;
+                double DD = (j < q - 1) ? d1prev - WR_ALPHA * (S2 + s2prev) : d1prev - (WR_ALPHA * 2) * s2prev;
+                out[(size_t)(2 * j) * sa] = s2prev;
+                if (2 * j + 1 < n) out[(size_t)(2 * j + 1) * sa] = DD;
+            }
+            dprev = d0; s1prev = S1; d1prev = D1; s2prev = S2;
+            lo = lo_nx; hi = hi_nx;
+        }
+    }
+}
+
+// box copy src -> dst (only needed when exactly one of the y/z passes was skipped)
+__global__ void k_copy_box(const double* __restrict__ src, double* __restrict__ dst, int n1, size_t sy,
+                           size_t sz)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n1) return;
+    size_t o = (size_t)x + (size_t)blockIdx.y * sy + (size_t)blockIdx.z * sz;
+    dst[o] = src[o];
+}
+
+static void launch_line_x(bool inv, double* X, int n, int n2, int n3, size_t sy, size_t sz, hipStream_t st)
+{
+    const int m = (n + 1) / 2;
+    const size_t per_line = (size_t)2 * (m + 1) * sizeof(double);
+    int R = (int)((48 * 1024) / per_line);  // <= 48 KiB of LDS per workgroup: 3 workgroups per CU
+    if (R < 1) R = 1;                       // lines up to 10239 samples fit the 160 KiB LDS
+    if (R > 64) R = 64;
+    const long long nlines = (long long)n2 * n3;
+    if (R > nlines) R = (int)nlines;
+    const size_t lds = per_line * R;
+    const int grid = cdiv(nlines, R);
+    if (inv) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_line_x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_line_x<true>, dim3(grid), dim3(256), lds, st, X, n, n2, n3, sy, sz, R);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_line_x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_line_x<false>, dim3(grid), dim3(256), lds, st, X, n, n2, n3, sy, sz, R);
+    }
+}
+
+// one y- or z-pass over the box (n1 x n2 x n3): axis 1 = y, 2 = z
+static void launch_stream(bool inv, const double* src, double* dst, int axis, int n1, int n2, int n3,
+                          size_t sy, size_t sz, hipStream_t st)
+{
+    const int n = axis == 1 ? n2 : n3;
+    const int nb = axis == 1 ? n3 : n2;
+    const size_t sa = axis == 1 ? sy : sz;
+    const size_t sb = axis == 1 ? sz : sy;
+    dim3 grid(cdiv(n1, 64), nb);
+    if (inv) hipLaunchKernelGGL(k_stream<true>, grid, dim3(64), 0, st, src, dst, n, sa, n1, sb);
+    else hipLaunchKernelGGL(k_stream<false>, grid, dim3(64), 0, st, src, dst, n, sa, n1, sb);
+}
+
+void transform(double* fld, double* scratch, int nx, int ny, int nz, int lvl, hipStream_t st)
+{
+    const size_t sy = (size_t)nx, sz = (size_t)nx * (size_t)ny;
+    auto up = [](int v, int p) { return v / p + (v % p ? 1 : 0); };
+    const int nl = lvl >= 0 ? lvl : -lvl;
+    for (int step = 0; step < nl; step++) {
+        // forward visits boxes ceil(n/1), ceil(n/2), ...; inverse visits them coarsest first
+        const int k = lvl >= 0 ? step : nl - 1 - step;
+        const int n1 = up(nx, 1 << k), n2 = up(ny, 1 << k), n3 = up(nz, 1 << k);
+        double* cur = fld;
+        double* oth = scratch;
+        auto stream_pass = [&](int axis) {
+            launch_stream(lvl < 0, cur, oth, axis, n1, n2, n3, sy, sz, st);
+            double* t = cur; cur = oth; oth = t;
+        };
+        if (lvl >= 0) {
+            if (n1 > 1) launch_line_x(false, cur, n1, n2, n3, sy, sz, st);
+            if (n2 > 1) stream_pass(1);
+            if (n3 > 1) stream_pass(2);
+        } else {
+            if (n3 > 1) stream_pass(2);
+            if (n2 > 1) stream_pass(1);
+            if (cur != fld) {  // bring the box home before the in-place x pass
+                hipLaunchKernelGGL(k_copy_box, dim3(cdiv(n1, 64), n2, n3), dim3(64), 0, st, cur, fld, n1, sy, sz);
+                cur = fld;
+            }
+            if (n1 > 1) launch_line_x(true, cur, n1, n2, n3, sy, sz, st);
+        }
+        if (cur != fld)
+            hipLaunchKernelGGL(k_copy_box, dim3(cdiv(n1, 64), n2, n3), dim3(64), 0, st, cur, fld, n1, sy, sz);
+    }
+}
+
+// =====================================================================================
+// reductions
+// =====================================================================================
+#define WR_RED_BLOCKS 2048
+#define WR_RED_THREADS 256
+
+int minmax_partials() { return WR_RED_BLOCKS; }
+
+// NaNs are skipped, as the reference's fmin/fmax scan does (wrappers.cpp:246-249)
+__device__ inline void mm_acc(double v, double& lo, double& hi)
+{
+    lo = fmin(lo, v);
+    hi = fmax(hi, v);
+}
+
+__device__ inline void block_minmax(double lo, double hi, double* __restrict__ partial)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    __shared__ double slo[WR_RED_THREADS / 64], shi[WR_RED_THREADS / 64];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { slo[w] = lo; shi[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < WR_RED_THREADS / 64; i++) { lo = fmin(lo, slo[i]); hi = fmax(hi, shi[i]); }
+        partial[2 * blockIdx.x] = lo;
+        partial[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+__global__ __launch_bounds__(WR_RED_THREADS) void k_minmax(const double* __restrict__ x, size_t n,
+                                                           double* __restrict__ partial)
+{
+    const double nan = __builtin_nan("");
+    double lo = nan, hi = nan;
+    const size_t n2 = n >> 1;
+    const double2* x2 = reinterpret_cast<const double2*>(x);  // hipMalloc'd base: 16-B aligned
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 v = x2[i];
+        mm_acc(v.x, lo, hi);
+        mm_acc(v.y, lo, hi);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) mm_acc(x[n - 1], lo, hi);
+    block_minmax(lo, hi, partial);
+}
+
+__global__ __launch_bounds__(WR_RED_THREADS) void k_minmax_final(const double* __restrict__ partial, int np,
+                                                                 double* __restrict__ result)
+{
+    const double nan = __builtin_nan("");
+    double lo = nan, hi = nan;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        lo = fmin(lo, partial[2 * i]);
+        hi = fmax(hi, partial[2 * i + 1]);
+    }
+    block_minmax(lo, hi, result);  // single block: lands in result[0], result[1]
+}
+
+static int red_grid(size_t n, int per_thread)
+{
+    long long g = cdiv((long long)n, (long long)WR_RED_THREADS * per_thread);
+    if (g < 1) g = 1;
+    if (g > WR_RED_BLOCKS) g = WR_RED_BLOCKS;
+    return (int)g;
+}
+
+void minmax(const double* x, size_t n, double* partial, double* result, hipStream_t st)
+{
+    const int g = red_grid(n, 2);
+    hipLaunchKernelGGL(k_minmax, dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, partial);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g, result);
+}
+
+__global__ void k_last_zero(const double* __restrict__ x, size_t n, unsigned long long* out)
+{
+    unsigned long long best = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (x[i] == 0.0) best = i + 1;  // grid-stride: i only grows, so the last hit is the largest
+    if (best) atomicMax(out, best);
+}
+
+void last_zero_index(const double* x, size_t n, unsigned long long* out, hipStream_t st)
+{
+    (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), st);
+    hipLaunchKernelGGL(k_last_zero, dim3(red_grid(n, 1)), dim3(WR_RED_THREADS), 0, st, x, n, out);
+}
+
+// =====================================================================================
+// quantizer plane, fused: q = (uchar)(aopt*x + bopt); r = x - (q*deps + minval); min/max(r)
+// Each lane handles 2 adjacent elements per step (16-B load, 2-B plane store, 16-B store).
+// =====================================================================================
+template <bool RESID>
+__global__ __launch_bounds__(WR_RED_THREADS) void k_quant(double* __restrict__ x, size_t n, double aopt,
+                                                          double bopt, double deps, double minval,
+                                                          uint8_t* __restrict__ q, double* __restrict__ partial)
+{
+    const double nan = __builtin_nan("");
+    double lo = nan, hi = nan;
+    const size_t n2 = n >> 1;
+    double2* x2 = reinterpret_cast<double2*>(x);
+    uchar2* q2 = reinterpret_cast<uchar2*>(q);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 v = x2[i];
+        // (unsigned char)(double): C truncation toward zero of a value in [0.5, 255.5]
+        const unsigned char qa = (unsigned char)(int)(aopt * v.x + bopt);
+        const unsigned char qb = (unsigned char)(int)(aopt * v.y + bopt);
+        q2[i] = make_uchar2(qa, qb);
+        if (RESID) {
+            v.x = v.x - ((double)qa * deps + minval);
+            v.y = v.y - ((double)qb * deps + minval);
+            x2[i] = v;
+            mm_acc(v.x, lo, hi);
+            mm_acc(v.y, lo, hi);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double v = x[n - 1];
+        const unsigned char qa = (unsigned char)(int)(aopt * v + bopt);
+        q[n - 1] = qa;
+        if (RESID) {
+            v = v - ((double)qa * deps + minval);
+            x[n - 1] = v;
+            mm_acc(v, lo, hi);
+        }
+    }
+    if (RESID) block_minmax(lo, hi, partial);
+}
+
+void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval, uint8_t* q,
+                    bool write_resid, double* partial, double* result, hipStream_t st)
+{
+    const int g = red_grid(n, 2);
+    if (write_resid) {
+        hipLaunchKernelGGL(k_quant<true>, dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, aopt, bopt, deps, minval, q, partial);
+        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g, result);
+    } else {
+        hipLaunchKernelGGL(k_quant<false>, dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, aopt, bopt, deps, minval, q, partial);
+    }
+}
+
+// =====================================================================================
+// decoder: acc = 0; for l in order: acc = acc + (q_l*deps_l + min_l)   (wrappers.cpp:480,513-514)
+// =====================================================================================
+__global__ __launch_bounds__(WR_RED_THREADS) void k_dequant(double* __restrict__ acc, size_t n, DequantParams p)
+{
+    const size_t n2 = n >> 1;
+    double2* a2 = reinterpret_cast<double2*>(acc);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            if (l < p.nlay) {
+                uchar2 qq = reinterpret_cast<const uchar2*>(p.q[l])[i];
+                a.x = a.x + ((double)qq.x * p.deps[l] + p.minval[l]);
+                a.y = a.y + ((double)qq.y * p.deps[l] + p.minval[l]);
+            }
+        }
+        a2[i] = a;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double a = 0.0;
+        for (int l = 0; l < p.nlay; l++) a = a + ((double)p.q[l][n - 1] * p.deps[l] + p.minval[l]);
+        acc[n - 1] = a;
+    }
+}
+
+void dequant_accum(double* acc, size_t n, const DequantParams& p, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dequant, dim3(red_grid(n, 2)), dim3(WR_RED_THREADS), 0, st, acc, n, p);
+}
+
+// =====================================================================================
+// helpers
+// =====================================================================================
+__global__ __launch_bounds__(WR_RED_THREADS) void k_linf(const double* __restrict__ a, const double* __restrict__ b,
+                                                         size_t n, double* __restrict__ partial)
+{
+    // reuses the min/max plumbing: "lo" carries -max|a-b| so that fmin keeps the largest diff
+    const double nan = __builtin_nan("");
+    double lo = nan, hi = nan;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        lo = fmin(lo, -fabs(a[i] - b[i]));
+        hi = fmax(hi, fabs(a[i]));
+    }
+    block_minmax(lo, hi, partial);
+}
+
+__global__ void k_neg0(double* r) { r[0] = -r[0]; }
+
+void linf_diff(const double* a, const double* b, size_t n, double* partial, double* result, hipStream_t st)
+{
+    const int g = red_grid(n, 1);
+    hipLaunchKernelGGL(k_linf, dim3(g), dim3(WR_RED_THREADS), 0, st, a, b, n, partial);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g, result);
+    hipLaunchKernelGGL(k_neg0, dim3(1), dim3(1), 0, st, result);
+}
+
+__global__ void k_fill(double* x, size_t n, double v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
+}
+
+void fill(double* x, size_t n, double v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fill, dim3(red_grid(n, 1)), dim3(WR_RED_THREADS), 0, st, x, n, v);
+}
+
+__device__ inline double tent(double t) { return 1.0 - fabs(2.0 * t - 1.0); }
+
+// bit-identical to waverange_amd/synth.py::field (IEEE + - * / floor only)
+__global__ void k_synth(double* __restrict__ out, int nx, int ny, int nz, unsigned long long seed, int z0, int z1)
+{
+    const size_t total = (size_t)nx * ny * (size_t)(z1 - z0);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % nx);
+        const int j = (int)((e / nx) % ny);
+        const int k = z0 + (int)(e / ((size_t)nx * ny));
+        const double u = (double)i / (double)nx, v = (double)j / (double)ny, w = (double)k / (double)nz;
+        const double tv = tent(v);
+        const double a = 10.0 * (4.0 * u * (1.0 - u)) * (tv * tv) * (1.0 - 2.0 * w);
+        const double u8 = 8.0 * u, v8 = 8.0 * v, w8 = 8.0 * w;
+        const double b = 0.1 * tent(u8 - floor(u8)) * tent(v8 - floor(v8)) * tent(w8 - floor(w8));
+        const unsigned long long lin = ((unsigned long long)k * ny + j) * nx + i;
+        unsigned long long z = seed + (lin + 1ull) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const double r = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+        const double c = 0.01 * (r - 0.5);
+        out[e] = (a + b) + c;
+    }
+}
+
+void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, int z0, int z1, hipStream_t st)
+{
+    const size_t total = (size_t)nx * ny * (size_t)(z1 - z0);
+    hipLaunchKernelGGL(k_synth, dim3(red_grid(total, 1)), dim3(WR_RED_THREADS), 0, st, out, nx, ny, nz, seed, z0, z1);
+}
+
+// one workgroup per 60000-symbol coding block: LDS histogram -> uint16[256]
+__global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, size_t n, uint16_t* __restrict__ hist)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t b0 = (size_t)blockIdx.x * 60000;
+    const size_t b1 = (b0 + 60000 < n) ? b0 + 60000 : n;
+    for (size_t i = b0 + threadIdx.x; i < b1; i += 256) atomicAdd(&h[q[i]], 1u);
+    __syncthreads();
+    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)h[threadIdx.x];
+}
+
+void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st)
+{
+    const int nb = (int)(n / 60000 + 1);  // includes the (possibly empty) final block
+    hipLaunchKernelGGL(k_hist, dim3(nb), dim3(256), 0, st, q, n, hist);
+}
+
+}  // namespace wrk

@@ -1,0 +1,27 @@
+// wr_rangecoder.h -- host-side plane bit-stream coder (product code).
+//
+// Bit-exact with the reference's per-plane stream: Schindler's rngcod13 primitives
+// (reference src/rangecod/rangecod.c:170-404) driven by the 60000-symbol block model of
+// src/core/wrappers.cpp:68-224.  The range coder stays on the host by design (it is one
+// serial recurrence per plane); planes are coded concurrently, one thread each.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace wrrc {
+
+constexpr uint32_t kBlock = 60000;  // reference src/core/defs.h:36
+
+// upper bound on the stream length for n symbols
+size_t encode_bound(size_t n);
+
+// Encode n symbols; `out` must hold encode_bound(n) bytes.  `hists`, when non-null, holds
+// per-block byte histograms (uint16[256] per block, n/60000+1 blocks) computed on the GPU.
+// Returns the stream length.
+size_t encode_plane(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hists);
+
+// Decode a stream into exactly n symbols.  Returns the number of symbols the stream held
+// (== n for a well-formed stream; never writes more than n symbols, never reads past len).
+size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n);
+
+}  // namespace wrrc
