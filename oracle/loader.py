@@ -28,7 +28,7 @@ def build(ref=True):
     """(Re)build the oracle and, when the reference sources are present, oracle/_ref."""
     subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     if ref and os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref", "cross"])
 
 
 def have_ref():

@@ -1,0 +1,70 @@
+"""Generic CLI (wrenc / wrdec) parity: .wrh text, .wrb bytes and the decoded file against the
+golden vectors produced by the compiled reference CLI (tools/make_golden_cli.py).
+
+  * CPU: OUR CLI sources linked against the REFERENCE codec (oracle/_ref/*_ours_refcodec) --
+    proves the file formats, the three parameter modes and the C-ABI call compatibility.
+  * GPU: OUR CLI on OUR library (waverange_amd/bin), and the REFERENCE's compiled CLI running
+    on OUR library under the reference's library name (oracle/_ref/*_ref_dyn) -- the drop-in.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import cli_cases
+from util import GOLDEN, ROOT
+
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+BINDIR = os.path.join(ROOT, "waverange_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def golden_cli():
+    with open(os.path.join(GOLDEN, "cli.json")) as fh:
+        return json.load(fh)
+
+
+def sha_file(p):
+    return hashlib.sha256(open(p, "rb").read()).hexdigest()
+
+
+def run_case(case, wrenc, wrdec, g):
+    env = dict(os.environ, WR_QUIET="1")
+    with tempfile.TemporaryDirectory() as d:
+        argv, stdin = cli_cases.write_inputs(case, d)
+        assert sha_file(os.path.join(d, "data.bin")) == g["input_sha256"]
+        subprocess.run([wrenc] + argv, cwd=d, input=stdin, text=True, check=True, stdout=subprocess.DEVNULL, env=env)
+        if os.path.exists(os.path.join(d, "inmeta")):
+            os.remove(os.path.join(d, "inmeta"))
+        assert open(os.path.join(d, "data.wrh")).read() == g["wrh"], "header text differs"
+        assert os.path.getsize(os.path.join(d, "data.wrb")) == g["wrb_size"]
+        assert sha_file(os.path.join(d, "data.wrb")) == g["wrb_sha256"], ".wrb bytes differ"
+        subprocess.run([wrdec] + cli_cases.dec_argv(case), cwd=d, check=True, stdout=subprocess.DEVNULL, env=env)
+        assert os.path.getsize(os.path.join(d, "datarec.bin")) == g["rec_size"]
+        assert sha_file(os.path.join(d, "datarec.bin")) == g["rec_sha256"], "decoded file differs"
+
+
+@pytest.mark.parametrize("case", sorted(cli_cases.CASES))
+def test_our_cli_on_reference_codec(case, golden_cli):
+    enc, dec = os.path.join(REFDIR, "wrenc_ours_refcodec"), os.path.join(REFDIR, "wrdec_ours_refcodec")
+    if not (os.path.exists(enc) and os.path.exists(dec)):
+        pytest.skip("oracle/_ref cross binaries not built")
+    run_case(case, enc, dec, golden_cli[case])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(cli_cases.CASES))
+def test_our_cli_on_gpu(case, golden_cli):
+    run_case(case, os.path.join(BINDIR, "wrenc"), os.path.join(BINDIR, "wrdec"), golden_cli[case])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["config1_64cube", "inmeta_new_type0"])
+def test_reference_cli_on_our_library(case, golden_cli):
+    enc, dec = os.path.join(REFDIR, "wrenc_ref_dyn"), os.path.join(REFDIR, "wrdec_ref_dyn")
+    if not (os.path.exists(enc) and os.path.exists(dec)):
+        pytest.skip("oracle/_ref/*_ref_dyn not built")
+    run_case(case, enc, dec, golden_cli[case])
