@@ -77,6 +77,7 @@ struct wr_ctx {
     double* d_scratch = nullptr; size_t scratch_elems = 0;
     uint8_t* d_planes = nullptr; size_t planes_bytes = 0;
     double* d_field = nullptr; size_t field_elems = 0;  // staging for the host-pointer API
+    double* d_lowbuf = nullptr; size_t lowbuf_elems = 0;  // compact low-pass boxes (fused transform)
     double* d_partial = nullptr; double* d_result = nullptr;
     unsigned long long* d_idx = nullptr;
     // pinned host
@@ -119,6 +120,33 @@ int ensure_host_planes(wr_ctx* c, size_t bytes)
     c->h_planes = nullptr; c->h_planes_bytes = 0;
     HIPCHK(hipHostMalloc(&c->h_planes, bytes, hipHostMallocDefault));
     c->h_planes_bytes = bytes;
+    return WR_OK;
+}
+
+int ensure_lowbuf(wr_ctx* c, size_t n)
+{
+    if (c->lowbuf_elems >= n) return WR_OK;
+    if (c->d_lowbuf) HIPCHK(hipFree(c->d_lowbuf));
+    c->d_lowbuf = nullptr; c->lowbuf_elems = 0;
+    HIPCHK(hipMalloc(&c->d_lowbuf, n * sizeof(double)));
+    c->lowbuf_elems = n;
+    return WR_OK;
+}
+
+// Forward transform of d_fld.  The fused path is out of place: the coefficients land in the
+// context's scratch buffer and *coef points there; the generic path works in place.
+int forward_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl, double** coef)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    if (int rc = ensure_scratch(c, n)) return rc;
+    *coef = d_fld;
+    if (lvl > 0 && wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED")) {
+        if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
+        wrk::transform_fwd_fused(d_fld, c->d_scratch, c->d_lowbuf, nx, ny, nz, c->stream);
+        *coef = c->d_scratch;
+    } else {
+        wrk::transform(d_fld, c->d_scratch, nx, ny, nz, lvl, c->stream);
+    }
     return WR_OK;
 }
 
@@ -271,7 +299,7 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy);
-    (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field);
+    (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field); (void)hipFree(c->d_lowbuf);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
     (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_planes);
     for (int i = 0; i < WR_NLAYMAX; i++) { (void)hipEventDestroy(c->ev_plane[i]); (void)hipEventDestroy(c->ev_copy[i]); }
@@ -345,8 +373,10 @@ int wr_dev_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl)
 {
     if (int rc = ctx_bind(c)) return rc;
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
-    if (int rc = ensure_scratch(c, (size_t)nx * ny * nz)) return rc;
-    wrk::transform(d_fld, c->d_scratch, nx, ny, nz, lvl, c->stream);
+    double* coef = nullptr;
+    if (int rc = forward_transform(c, d_fld, nx, ny, nz, lvl, &coef)) return rc;  // handles lvl < 0 too
+    if (coef != d_fld)
+        HIPCHK(hipMemcpyAsync(d_fld, coef, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipGetLastError());
     return WR_OK;
 }
@@ -416,7 +446,8 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
         return WR_OK;
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    wrk::transform(d_fld, c->d_scratch, nx, ny, nz, (int)info->wlev, c->stream);
+    double* const d_in = d_fld;
+    if (int rc = forward_transform(c, d_in, nx, ny, nz, (int)info->wlev, &d_fld)) return rc;  // d_fld := coefficients
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     if (verbose()) printf("Range encoding...\n");
     info->tolabs = abs_tolerance(tolrel, p);
@@ -457,6 +488,8 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
     }
     info->nlay = (unsigned char)ilay;
     if (tm) tm->quant_ms = quant_ms;
+    if (c->keep_residual && d_fld != d_in)  // leave the residual where the reference leaves it
+        HIPCHK(hipMemcpyAsync(d_in, d_fld, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return WR_OK;
 }
 

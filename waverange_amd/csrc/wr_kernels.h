@@ -50,3 +50,14 @@ void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, i
 void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st);
 
 }  // namespace wrk
+
+namespace wrk {
+// ---- fused single-pass-per-level transform (wr_fused.hip).  Usable when every level's box
+// is even in all three directions: nx, ny, nz multiples of 16 and >= 64 (fused_ok()).
+// Out of place: reads `src` (left untouched), writes all coefficients to `dst`; `lowbuf`
+// is work space for the compact low-pass boxes of levels 1..3 (fused_lowbuf_elems() doubles).
+bool fused_ok(int nx, int ny, int nz, int lvl);
+size_t fused_lowbuf_elems(int nx, int ny, int nz);
+void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
+void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
+}  // namespace wrk
