@@ -1,20 +1,21 @@
 // wr_fused.hip -- one launch per level: the 3-D CDF-9/7 lifting of a whole level in a single
 // pass over HBM (reference src/waveletcdf97_3d/waveletcdf97_3d.c:73-276 forward, :281-466 inverse).
 //
-// Decomposition (forward): a workgroup of 1024 threads owns an xy tile of 128 x 32 samples
-// (64 x-pairs x 16 y-pairs; thread = one x-pair x one y-pair = 4 output points) and marches
+// Decomposition (forward): a workgroup of 512 threads owns an xy tile of 128 x 32 samples
+// (64 x-pairs x 16 y-pairs; thread = one x-pair x two y-pairs = 8 output points) and marches
 // along z over a segment of z-pairs:
 //   * the two input planes of z-pair t (tile + halo: 4 samples before, 3 after, in x and y)
-//     are staged through registers into LDS; at the domain edges the halo is filled by
+//     stream from global memory straight into LDS (global_load_lds, no register staging) while
+//     the previous pair is being computed; at the domain edges the halo is filled by
 //     whole-sample mirroring, which reproduces the reference's doubled boundary terms bit
 //     for bit (c*(v+v) == (2c)*v), so the tile code has no edge branches;
 //   * x lifting: every (row, x-pair) recomputes its 4-stage chain from 5 raw pairs in LDS
 //     (no barrier between stages), writes [low | high] halves of the row to a second buffer;
-//   * y lifting: the same recomputation down the columns, 9 rows -> one y-pair, result in
-//     registers: 4 values (LL, HL, LH, HH) per plane per thread;
+//   * y lifting: the same recomputation down the columns, 11 rows -> two y-pairs, result in
+//     registers: 8 values (LL, HL, LH, HH of both pairs) per plane per thread;
 //   * z lifting: streaming register pipeline (as k_stream), 5 doubles of state per point;
 //     a segment that starts mid-volume warms the pipeline up on 2 extra z-pairs;
-//   * 8 coalesced stores per thread and step, straight to the final octant positions; the
+//   * 16 coalesced stores per thread and step, straight to the final octant positions; the
 //     low-pass octant goes to a compact buffer that is the next level's input, so no level
 //     reads what another workgroup of the same launch writes (no in-place hazard).
 // Halo recomputation is bit-safe: every output is a fixed expression tree of its inputs.
@@ -38,7 +39,8 @@ constexpr int TYP = 16;             // y-pairs per tile
 constexpr int RX = TXP + 4;         // raw pairs per staged row: 2 + 64 + 2
 constexpr int RROWS = 2 * TYP + 7;  // staged rows: 4 + 32 + 3
 constexpr int NCHUNK = RROWS * RX;  // 16-byte chunks per plane (2652)
-constexpr int NTHR = 1024;
+constexpr int NTHR = 512;
+constexpr int NWAVE = NTHR / 64;
 constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (3)
 constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * 2 * TXP * 8;
 
@@ -66,6 +68,28 @@ __device__ inline void lift_fwd_center(const double s[5], const double d[4], dou
     hi = d2c * WR_IZETA;
 }
 
+// forward lifting of two adjacent pairs from s[-2..3], d[-2..2]: 14 lifting steps instead of 20
+__device__ inline void lift_fwd_two(const double s[6], const double d[5], double& lo0, double& hi0, double& lo1,
+                                    double& hi1)
+{
+    const double d1a = d[0] + WR_ALPHA * (s[1] + s[0]);
+    const double d1b = d[1] + WR_ALPHA * (s[2] + s[1]);
+    const double d1c = d[2] + WR_ALPHA * (s[3] + s[2]);
+    const double d1d = d[3] + WR_ALPHA * (s[4] + s[3]);
+    const double d1e = d[4] + WR_ALPHA * (s[5] + s[4]);
+    const double s1b = s[1] + WR_BETA * (d1b + d1a);
+    const double s1c = s[2] + WR_BETA * (d1c + d1b);
+    const double s1d = s[3] + WR_BETA * (d1d + d1c);
+    const double s1e = s[4] + WR_BETA * (d1e + d1d);
+    const double d2b = d1b + WR_GAMMA * (s1c + s1b);
+    const double d2c = d1c + WR_GAMMA * (s1d + s1c);
+    const double d2d = d1d + WR_GAMMA * (s1e + s1d);
+    const double s2c = s1c + WR_DELTA * (d2c + d2b);
+    const double s2d = s1d + WR_DELTA * (d2d + d2c);
+    lo0 = s2c * WR_ZETA; hi0 = d2c * WR_IZETA;
+    lo1 = s2d * WR_ZETA; hi1 = d2d * WR_IZETA;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(NTHR) void k_fwd_fused(
@@ -85,42 +109,52 @@ __global__ __launch_bounds__(NTHR) void k_fwd_fused(
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
 
-    // per-thread source offsets of its staged chunks (same for every plane)
-    int offa[KCH], offb[KCH];
+    // per-thread source offsets of its staged 16-byte chunks (same for every plane).  Rows are
+    // mirrored at the y edges by choosing the source row; a chunk that would need x mirroring
+    // loads any valid address and is patched in LDS by the x-lifting wave (see xlift).
+    int offa[KCH];
 #pragma unroll
     for (int k = 0; k < KCH; k++) {
         const int c = tid + NTHR * k;
         const int row = c / RX, pr = c - row * RX;
         const int gy = mirror(2 * py0 - 4 + row, n2);
-        const int gx = 2 * (px0 - 2 + pr);
-        offa[k] = (int)(gy * s_sy) + mirror(gx, n1);
-        offb[k] = (int)(gy * s_sy) + mirror(gx + 1, n1);
+        int gx = 2 * (px0 - 2 + pr);
+        gx = gx < 0 ? 0 : (gx > n1 - 2 ? n1 - 2 : gx);
+        offa[k] = (int)(gy * s_sy) + gx;
     }
-    double2 stA[KCH], stB[KCH];
-    auto fetch = [&](int t) {
-        const double* pa = src + (size_t)(2 * t) * s_sz;
-        const double* pb = pa + s_sz;
+    // global -> LDS without a register round trip: each lane supplies its own 16-byte source,
+    // the wave's 64 chunks land contiguously at a wave-uniform LDS base (global_load_lds_dwordx4)
+    auto fetch = [&](int t, int p) {
+        const double* pl = src + (size_t)(2 * t + p) * s_sz;
 #pragma unroll
         for (int k = 0; k < KCH; k++) {
             if (tid + NTHR * k < NCHUNK) {
-                if (offb[k] == offa[k] + 1) {
-                    stA[k] = *reinterpret_cast<const double2*>(pa + offa[k]);
-                    stB[k] = *reinterpret_cast<const double2*>(pb + offa[k]);
-                } else {
-                    stA[k] = make_double2(pa[offa[k]], pa[offb[k]]);
-                    stB[k] = make_double2(pb[offa[k]], pb[offb[k]]);
-                }
+                double2* l = raw + p * NCHUNK + NTHR * k + (w << 6);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl + offa[k]),
+                                                 (__attribute__((address_space(3))) void*)l, 16, 0, 0);
             }
         }
     };
+    const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
+    const int iL = m1 - 1 - px0;  // local index of the last x-pair of the domain (right-edge tiles)
 
     // x lifting of every staged row of plane p -> xl
     auto xlift = [&](int p) {
         const double2* rp = raw + p * NCHUNK;
 #pragma unroll
-        for (int k = 0; k < (RROWS + 15) / 16; k++) {
-            const int row = w + 16 * k;
+        for (int k = 0; k < (RROWS + NWAVE - 1) / NWAVE; k++) {
+            const int row = w + NWAVE * k;
             if (row < RROWS) {
+                // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
+                // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3])
+                if (left_edge && lane < 2) {
+                    double2* e = const_cast<double2*>(rp) + row * RX;
+                    e[lane] = lane ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
+                }
+                if (right_edge && lane < 2) {
+                    double2* e = const_cast<double2*>(rp) + row * RX + iL + 3 + lane;
+                    e[0] = lane ? make_double2(e[-3].x, e[-4].y) : make_double2(e[-1].x, e[-2].y);
+                }
                 const double2* r = rp + row * RX + lane;
                 const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
                 const double s[5] = {v0.x, v1.x, v2.x, v3.x, v4.x};
@@ -132,53 +166,53 @@ __global__ __launch_bounds__(NTHR) void k_fwd_fused(
             }
         }
     };
-    // y lifting of this thread's y-pair for its two x columns: out = {LL, HL, LH, HH}
-    auto ylift = [&](double out[4]) {
-        const double* c0 = xl + (2 * w) * (2 * TXP) + lane;
+    // y lifting of this thread's two y-pairs (2w, 2w+1) for its two x columns:
+    // out[4*yp + {0,1,2,3}] = {LL, HL, LH, HH} of y-pair yp
+    auto ylift = [&](double out[8]) {
+        const double* c0 = xl + (4 * w) * (2 * TXP) + lane;
+        constexpr int P = 2 * TXP;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const double* c = c0 + h * TXP;
-            const double s[5] = {c[0], c[2 * 2 * TXP], c[4 * 2 * TXP], c[6 * 2 * TXP], c[8 * 2 * TXP]};
-            const double d[4] = {c[1 * 2 * TXP], c[3 * 2 * TXP], c[5 * 2 * TXP], c[7 * 2 * TXP]};
-            lift_fwd_center(s, d, out[h], out[2 + h]);
+            const double s[6] = {c[0], c[2 * P], c[4 * P], c[6 * P], c[8 * P], c[10 * P]};
+            const double d[5] = {c[1 * P], c[3 * P], c[5 * P], c[7 * P], c[9 * P]};
+            lift_fwd_two(s, d, out[h], out[2 + h], out[4 + h], out[6 + h]);
         }
     };
 
-    // z pipeline state of the 4 points (see k_stream in wr_kernels.hip)
-    double sr1[4] = {0, 0, 0, 0}, dr1[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0},
-           p2[4] = {0, 0, 0, 0};
-    const int ox = px0 + lane, oy = py0 + w;
-    const bool owner = ox < m1 && oy < m2;
-    // octant bases of the 4 points: {LL, HL, LH, HH} in (x, y)
-    size_t pos[4];
-    pos[0] = (size_t)ox + (size_t)oy * d_sy;
-    pos[1] = (size_t)(m1 + ox) + (size_t)oy * d_sy;
-    pos[2] = (size_t)ox + (size_t)(m2 + oy) * d_sy;
-    pos[3] = (size_t)(m1 + ox) + (size_t)(m2 + oy) * d_sy;
-    const size_t lpos = (size_t)ox + (size_t)oy * l_sy;
-
-    if (tb < m3) fetch(tb);
-    for (int t = tb; t <= te; t++) {
-        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-        if (t < m3) {  // block-uniform
+    // z pipeline state of the 8 points (see k_stream in wr_kernels.hip)
+    double sr1[8], dr1[8], p1[8], q1[8], p2[8];
 #pragma unroll
-            for (int k = 0; k < KCH; k++) {
-                const int c = tid + NTHR * k;
-                if (c < NCHUNK) { raw[c] = stA[k]; raw[NCHUNK + c] = stB[k]; }
-            }
-            __syncthreads();
-            if (t + 1 <= te && t + 1 < m3) fetch(t + 1);  // in flight during this step's compute
+    for (int q = 0; q < 8; q++) sr1[q] = dr1[q] = p1[q] = q1[q] = p2[q] = 0.0;
+    const int ox = px0 + lane, oy = py0 + 2 * w;
+    const bool own_x = ox < m1;
+    // element offsets of the points inside a z-plane, all 32-bit on top of wave-uniform bases
+    const unsigned pos0 = (unsigned)ox + (unsigned)oy * (unsigned)d_sy;
+    const unsigned lpos = (unsigned)ox + (unsigned)oy * (unsigned)l_sy;
+    const size_t oct_x = (size_t)m1, oct_y = (size_t)m2 * d_sy;
+
+    if (tb < m3) { fetch(tb, 0); fetch(tb, 1); }
+    for (int t = tb; t <= te; t++) {
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = b[q] = 0.0;
+        if (t < m3) {  // block-uniform
+            const bool more = t + 1 <= te && t + 1 < m3;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of planes 2t, 2t+1 have landed
+            __syncthreads();                      // ... and everybody else's
             xlift(0);
             __syncthreads();
+            if (more) fetch(t + 1, 0);  // raw[0] is free again: next even plane streams in behind the compute
             ylift(a);
             __syncthreads();
             xlift(1);
             __syncthreads();
+            if (more) fetch(t + 1, 1);
             ylift(b);
         }
         // ---- z step: (a, b) is z-pair t  (waveletcdf97_3d.c:228-262)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 8; q++) {
             double D1 = 0, S1 = 0;
             if (t >= 1 && t <= m3) {
                 const int j = t - 1;
@@ -189,10 +223,13 @@ __global__ __launch_bounds__(NTHR) void k_fwd_fused(
                 const int j = t - 2;
                 const double D2 = (j < m3 - 1) ? p1[q] + WR_GAMMA * (S1 + q1[q]) : p1[q] + (WR_GAMMA * 2) * q1[q];
                 const double S2 = (j > 0) ? q1[q] + WR_DELTA * (D2 + p2[q]) : q1[q] + (WR_DELTA * 2) * D2;
-                if (owner && j >= z0 && j < z1) {
-                    if (q == 0) low[lpos + (size_t)j * l_sz] = S2 * WR_ZETA;
-                    else dst[pos[q] + (size_t)j * d_sz] = S2 * WR_ZETA;
-                    dst[pos[q] + (size_t)(m3 + j) * d_sz] = D2 * WR_IZETA;
+                const int yp = q >> 2;  // which of the two y-pairs
+                if (own_x && oy + yp < m2 && j >= z0 && j < z1) {
+                    // wave-uniform plane bases, per-lane 32-bit offsets
+                    double* base = dst + ((q & 1) ? oct_x : 0) + ((q & 2) ? oct_y : 0) + (size_t)yp * d_sy;
+                    if ((q & 3) == 0) (low + (size_t)j * l_sz + (size_t)yp * l_sy)[lpos] = S2 * WR_ZETA;
+                    else (base + (size_t)j * d_sz)[pos0] = S2 * WR_ZETA;
+                    (base + (size_t)(m3 + j) * d_sz)[pos0] = D2 * WR_IZETA;
                 }
                 p2[q] = D2;
             }
