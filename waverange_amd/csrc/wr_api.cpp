@@ -140,13 +140,33 @@ int forward_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl,
     const size_t n = (size_t)nx * ny * nz;
     if (int rc = ensure_scratch(c, n)) return rc;
     *coef = d_fld;
-    if (lvl > 0 && wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED")) {
+    if (wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED")) {
         if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
-        wrk::transform_fwd_fused(d_fld, c->d_scratch, c->d_lowbuf, nx, ny, nz, c->stream);
+        if (lvl > 0) wrk::transform_fwd_fused(d_fld, c->d_scratch, c->d_lowbuf, nx, ny, nz, c->stream);
+        else wrk::transform_inv_fused(d_fld, c->d_scratch, c->d_lowbuf, nx, ny, nz, c->stream);
         *coef = c->d_scratch;
     } else {
         wrk::transform(d_fld, c->d_scratch, nx, ny, nz, lvl, c->stream);
     }
+    return WR_OK;
+}
+
+// decoder back end: acc = sum of planes, then the inverse transform, result in d_fld.
+// Fused path: accumulate into the scratch buffer and transform out of place into d_fld.
+// Records ev_a / ev_b / ev_c around the two stages (for the timings) when tm is given.
+int inverse_from_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wlev, const wrk::DequantParams& p,
+                        wr_timings* tm)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    if (int rc = ensure_scratch(c, n)) return rc;
+    const bool fused = wlev == 4 && wrk::fused_ok(nx, ny, nz, -4) && !getenv("WR_NO_FUSED");
+    if (fused) if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
+    if (tm) HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    wrk::dequant_accum(fused ? c->d_scratch : d_fld, n, p, c->stream);
+    if (tm) HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (fused) wrk::transform_inv_fused(c->d_scratch, d_fld, c->d_lowbuf, nx, ny, nz, c->stream);
+    else wrk::transform(d_fld, c->d_scratch, nx, ny, nz, -wlev, c->stream);
+    if (tm) HIPCHK(hipEventRecord(c->ev_c, c->stream));
     return WR_OK;
 }
 
@@ -533,8 +553,7 @@ int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const
         p.deps[l] = info->deps_vec[l];
         p.minval[l] = info->minval_vec[l];
     }
-    wrk::dequant_accum(d_fld, n, p, c->stream);
-    wrk::transform(d_fld, c->d_scratch, nx, ny, nz, -(int)info->wlev, c->stream);
+    if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, nullptr)) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return WR_OK;
@@ -679,11 +698,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     memset(&p, 0, sizeof p);
     p.nlay = nlay;
     for (int l = 0; l < nlay; l++) { p.q[l] = c->d_planes + l * pitch; p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; }
-    HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    wrk::dequant_accum(d_fld, n, p, c->stream);
-    HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    wrk::transform(d_fld, c->d_scratch, nx, ny, nz, -(int)info->wlev, c->stream);
-    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -707,8 +722,10 @@ int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     if (reps < 1) return fail(WR_ERR_ARG, "reps < 1");
     if (int rc = ensure_scratch(c, (size_t)nx * ny * nz)) return rc;
+    double* coef = nullptr;
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    for (int r = 0; r < reps; r++) wrk::transform(d_fld, c->d_scratch, nx, ny, nz, lvl, c->stream);
+    for (int r = 0; r < reps; r++)
+        if (int rc = forward_transform(c, d_fld, nx, ny, nz, lvl, &coef)) return rc;  // fused: result stays in scratch
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventSynchronize(c->ev_b));

@@ -238,9 +238,256 @@ __global__ __launch_bounds__(NTHR) void k_fwd_fused(
     }
 }
 
+
+// =====================================================================================
+// Inverse level (waveletcdf97_3d.c:281-466): z, then y, then x.
+//   * the coefficient planes of z-pair t (low-z plane t, high-z plane q3+t; per plane the four
+//     xy quadrants LL/HL/LH/HH of the tile + 2 halo pairs on every side, i.e. 4 x 20 x 68
+//     doubles) stream global -> LDS; halo ROWS are mirrored by choosing the source row;
+//   * z: pointwise streaming register pipeline on every staged point (tile + halo), 4 doubles
+//     of state per point; the even output plane goes to LDS, the odd one waits in registers;
+//   * y: each wave rebuilds the 4 output rows of its two y-pairs for all 136 coefficient
+//     columns by recomputation from 11 rows (wave-private LDS rows, no workgroup barrier);
+//   * x: mirrored halo COLUMNS are patched in those rows (x mirroring commutes with the
+//     pointwise z and y steps), then every lane rebuilds one x-pair per row and stores 16 B.
+// =====================================================================================
+namespace {
+constexpr int HX = TXP + 4;              // coefficient columns per quadrant row (68)
+constexpr int HY = TYP + 4;              // coefficient rows per quadrant (20)
+constexpr int CROW = HX / 2;             // 16-byte chunks per row (34)
+constexpr int NCI = 4 * HY * CROW;       // chunks per plane (2720)
+constexpr int KCI = (NCI + NTHR - 1) / NTHR;  // chunk slots per thread (6)
+constexpr size_t LDS_INV = (size_t)3 * NCI * 16 + (size_t)NWAVE * 2 * (2 * HX) * 8;
+
+// whole-sample symmetric extension in coefficient space (even length 2M):
+//   low-pass  s[-k] = s[k],    s[M-1+k] = s[M-k]
+//   high-pass d[-k] = d[k-1],  d[M-1+k] = d[M-1-k]
+__device__ inline int mirror_s(int k, int M) { if (k < 0) k = -k; if (k >= M) k = 2 * M - 1 - k; return k < 0 ? 0 : (k >= M ? M - 1 : k); }
+__device__ inline int mirror_d(int k, int M) { if (k < 0) k = -k - 1; if (k >= M) k = 2 * M - 2 - k; return k < 0 ? 0 : (k >= M ? M - 1 : k); }
+
+// inverse lifting of the centre pair from s[-1..2], d[-2..2] (unscaled inputs)  (:312-337)
+__device__ inline void lift_inv_center(const double sr[4], const double dr[5], double& even, double& odd)
+{
+    double s[4], d[5];
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = sr[k] * WR_IZETA;
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = dr[k] * WR_ZETA;
+    const double s1a = s[0] - WR_DELTA * (d[1] + d[0]);
+    const double s1b = s[1] - WR_DELTA * (d[2] + d[1]);
+    const double s1c = s[2] - WR_DELTA * (d[3] + d[2]);
+    const double s1d = s[3] - WR_DELTA * (d[4] + d[3]);
+    const double d1a = d[1] - WR_GAMMA * (s1b + s1a);
+    const double d1b = d[2] - WR_GAMMA * (s1c + s1b);
+    const double d1c = d[3] - WR_GAMMA * (s1d + s1c);
+    const double s2b = s1b - WR_BETA * (d1b + d1a);
+    const double s2c = s1c - WR_BETA * (d1c + d1b);
+    even = s2b;
+    odd = d1b - WR_ALPHA * (s2c + s2b);
+}
+
+// two adjacent pairs from s[-1..3], d[-2..3]: 14 lifting steps
+__device__ inline void lift_inv_two(const double sr[5], const double dr[6], double out[4])
+{
+    double s[5], d[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) s[k] = sr[k] * WR_IZETA;
+#pragma unroll
+    for (int k = 0; k < 6; k++) d[k] = dr[k] * WR_ZETA;
+    double s1[5], d1[4], s2[3];
+#pragma unroll
+    for (int k = 0; k < 5; k++) s1[k] = s[k] - WR_DELTA * (d[k + 1] + d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) d1[k] = d[k + 1] - WR_GAMMA * (s1[k + 1] + s1[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) s2[k] = s1[k + 1] - WR_BETA * (d1[k + 1] + d1[k]);
+    out[0] = s2[0];
+    out[1] = d1[1] - WR_ALPHA * (s2[1] + s2[0]);
+    out[2] = s2[1];
+    out[3] = d1[2] - WR_ALPHA * (s2[2] + s2[1]);
+}
+}  // namespace
+
+__global__ __launch_bounds__(NTHR) void k_inv_fused(
+    const double* __restrict__ src, size_t s_sy, size_t s_sz,  // coefficient array (detail octants)
+    const double* __restrict__ low, size_t l_sy, size_t l_sz,  // low-pass octant (previous level's output)
+    double* __restrict__ out, size_t o_sy, size_t o_sz,        // reconstructed box of this level
+    int n1, int n2, int n3, int zps)
+{
+    extern __shared__ double2 lds2[];
+    double2* in = lds2;                   // [2][NCI]   staged low-z / high-z coefficient planes
+    double2* zb = lds2 + 2 * NCI;         // [NCI]      one z-reconstructed plane
+    double* yb = reinterpret_cast<double*>(lds2 + 3 * NCI);  // [NWAVE][2][2*HX] wave-private rows
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
+    const int tiles_x = (m1 + TXP - 1) / TXP;
+    const int px0 = (blockIdx.x % tiles_x) * TXP, py0 = (blockIdx.x / tiles_x) * TYP;
+    const int z0 = blockIdx.y * zps;
+    const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
+    const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
+
+    // source offsets of this thread's chunk slots inside a z-plane
+    int offL[KCI], offH[KCI];
+    unsigned lll_mask = 0;
+#pragma unroll
+    for (int k = 0; k < KCI; k++) {
+        const int c = tid + NTHR * k;
+        const int q = c / (HY * CROW), rem = c - q * (HY * CROW);
+        const int row = rem / CROW, cc = rem - row * CROW;
+        const int gyp = (q & 2) ? mirror_d(py0 - 2 + row, m2) : mirror_s(py0 - 2 + row, m2);
+        int gxp = px0 - 2 + 2 * cc;
+        gxp = gxp < 0 ? 0 : (gxp > m1 - 2 ? m1 - 2 : gxp);  // x-mirrored columns are patched later
+        const int so = (int)(((q & 2) ? m2 + gyp : gyp) * s_sy) + ((q & 1) ? m1 : 0) + gxp;
+        offH[k] = so;
+        offL[k] = (q == 0) ? (int)(gyp * l_sy) + gxp : so;
+        if (q == 0) lll_mask |= 1u << k;
+    }
+    auto fetch = [&](int t) {
+        const double* pl = src + (size_t)t * s_sz;         // low-z plane, detail quadrants
+        const double* pll = low + (size_t)t * l_sz;        // low-z plane, LL quadrant
+        const double* ph = src + (size_t)(m3 + t) * s_sz;  // high-z plane
+#pragma unroll
+        for (int k = 0; k < KCI; k++) {
+            if (tid + NTHR * k < NCI) {
+                double2* l0 = in + NTHR * k + (w << 6);
+                const double* gl = ((lll_mask >> k) & 1) ? pll + offL[k] : pl + offL[k];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
+                                                 (__attribute__((address_space(3))) void*)l0, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ph + offH[k]),
+                                                 (__attribute__((address_space(3))) void*)(l0 + NCI), 16, 0, 0);
+            }
+        }
+    };
+
+    const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
+    const int iL = m1 - 1 - px0;
+    double* ybw = yb + w * (2 * 2 * HX);  // this wave's two rows of [xlow 68 | xhigh 68]
+    const int J = 2 * w;                   // first of this wave's two local y-pairs
+
+    // x stage on the wave's two staged rows: patch mirrored halo columns, rebuild, store
+    auto xstage = [&](int zplane, int yrow0) {
+        if (left_edge && lane < 4) {
+            double* r = ybw + (lane >> 1) * (2 * HX);
+            if (lane & 1) { r[0] = r[4]; r[1] = r[3]; }              // s[-2] = s[2], s[-1] = s[1]
+            else { r[HX + 0] = r[HX + 3]; r[HX + 1] = r[HX + 2]; }   // d[-2] = d[1], d[-1] = d[0]
+        }
+        if (right_edge && lane < 4) {
+            double* r = ybw + (lane >> 1) * (2 * HX);
+            if (lane & 1) { r[iL + 3] = r[iL + 2]; r[iL + 4] = r[iL + 1]; }            // s[m] = s[m-1], s[m+1] = s[m-2]
+            else { r[HX + iL + 3] = r[HX + iL + 1]; r[HX + iL + 4] = r[HX + iL]; }     // d[m] = d[m-2], d[m+1] = d[m-3]
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const double* row = ybw + r * (2 * HX);
+            const double sr[4] = {row[lane + 1], row[lane + 2], row[lane + 3], row[lane + 4]};
+            const double dr[5] = {row[HX + lane], row[HX + lane + 1], row[HX + lane + 2], row[HX + lane + 3],
+                                  row[HX + lane + 4]};
+            double ev, od;
+            lift_inv_center(sr, dr, ev, od);
+            const int y = yrow0 + r;
+            if (px0 + lane < m1 && y < n2)
+                *reinterpret_cast<double2*>(out + (size_t)zplane * o_sz + (size_t)y * o_sy + 2 * (px0 + lane)) =
+                    make_double2(ev, od);
+        }
+    };
+    // y + x stages of the z-plane held in zb
+    auto yxstage = [&](int zplane) {
+        double keep[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int cid = lane + 64 * p;
+            if (cid < 2 * HX) {
+                const int xh = cid >= HX;             // 0: x-low column, 1: x-high column
+                const int col = cid - xh * HX;
+                const double* zl = reinterpret_cast<const double*>(zb) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
+                const double* zh = reinterpret_cast<const double*>(zb) + (size_t)(2 + xh) * (HY * HX) + col;    // y-high quadrant
+                // local row of y-pair k is k + 2:  s[J-1..J+3] -> rows J+1..J+5,  d[J-2..J+3] -> rows J..J+5
+                const double sr[5] = {zl[(J + 1) * HX], zl[(J + 2) * HX], zl[(J + 3) * HX], zl[(J + 4) * HX], zl[(J + 5) * HX]};
+                const double dr[6] = {zh[(J + 0) * HX], zh[(J + 1) * HX], zh[(J + 2) * HX], zh[(J + 3) * HX], zh[(J + 4) * HX],
+                                      zh[(J + 5) * HX]};
+                double o[4];
+                lift_inv_two(sr, dr, o);
+                ybw[cid] = o[0];
+                ybw[2 * HX + cid] = o[1];
+                keep[p][0] = o[2];
+                keep[p][1] = o[3];
+            }
+        }
+        xstage(zplane, 2 * (py0 + J));
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int cid = lane + 64 * p;
+            if (cid < 2 * HX) { ybw[cid] = keep[p][0]; ybw[2 * HX + cid] = keep[p][1]; }
+        }
+        xstage(zplane, 2 * (py0 + J) + 2);
+    };
+
+    // z pipeline state per staged point: 2 points per chunk slot
+    double dprev[KCI][2], s1prev[KCI][2], d1prev[KCI][2], s2prev[KCI][2];
+#pragma unroll
+    for (int k = 0; k < KCI; k++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) dprev[k][e] = s1prev[k][e] = d1prev[k][e] = s2prev[k][e] = 0.0;
+
+    if (tb < m3) fetch(tb);
+    for (int t = tb; t <= te; t++) {
+        const int j = t - 2;
+        const bool emit = j >= z0 && j < z1;  // block-uniform
+        double2 odd[KCI];
+        if (t < m3) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed
+        __syncthreads();  // everybody's chunks have landed; the previous step's readers of zb are done
+        // ---- z step on every staged point  (waveletcdf97_3d.c:312-337 along z)
+#pragma unroll
+        for (int k = 0; k < KCI; k++) {
+            const int c = tid + NTHR * k;
+            if (c < NCI) {
+                double lo[2] = {0, 0}, hi[2] = {0, 0};
+                if (t < m3) {
+                    const double2 vl = in[c], vh = in[NCI + c];
+                    lo[0] = vl.x; lo[1] = vl.y; hi[0] = vh.x; hi[1] = vh.y;
+                }
+                double ev[2], od[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    double d0 = 0, S1 = 0, D1 = 0, S2 = 0;
+                    if (t < m3) {
+                        const double s0 = lo[e] * WR_IZETA;
+                        d0 = hi[e] * WR_ZETA;
+                        S1 = (t > 0) ? s0 - WR_DELTA * (d0 + dprev[k][e]) : s0 - (WR_DELTA * 2) * d0;
+                    }
+                    if (t >= 1 && t <= m3) {
+                        const int jj = t - 1;
+                        D1 = (jj < m3 - 1) ? dprev[k][e] - WR_GAMMA * (S1 + s1prev[k][e])
+                                           : dprev[k][e] - (WR_GAMMA * 2) * s1prev[k][e];
+                        S2 = (jj > 0) ? s1prev[k][e] - WR_BETA * (D1 + d1prev[k][e]) : s1prev[k][e] - (WR_BETA * 2) * D1;
+                    }
+                    ev[e] = s2prev[k][e];
+                    od[e] = (j < m3 - 1) ? d1prev[k][e] - WR_ALPHA * (S2 + s2prev[k][e])
+                                         : d1prev[k][e] - (WR_ALPHA * 2) * s2prev[k][e];
+                    dprev[k][e] = d0; s1prev[k][e] = S1; d1prev[k][e] = D1; s2prev[k][e] = S2;
+                }
+                if (emit) zb[c] = make_double2(ev[0], ev[1]);
+                odd[k] = make_double2(od[0], od[1]);
+            }
+        }
+        __syncthreads();  // zb complete; `in` fully consumed
+        if (t + 1 <= te && t + 1 < m3) fetch(t + 1);  // streams in behind the y/x stages
+        if (emit) {
+            yxstage(2 * j);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KCI; k++)
+                if (tid + NTHR * k < NCI) zb[tid + NTHR * k] = odd[k];
+            __syncthreads();
+            yxstage(2 * j + 1);
+        }
+    }
+}
+
 bool fused_ok(int nx, int ny, int nz, int lvl)
 {
     if (lvl != 4 && lvl != -4) return false;
+    if (lvl < 0 && nx % 32 != 0) return false;  // inverse: the x-high half must start 16-byte aligned at every level
     return nx % 16 == 0 && ny % 16 == 0 && nz % 16 == 0 && nx >= 64 && ny >= 64 && nz >= 64 &&
            (size_t)nx * ny < (1u << 30);
 }
@@ -288,6 +535,35 @@ void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx,
     }
 }
 
-void transform_inv_fused(const double*, double*, double*, int, int, int, hipStream_t) {}
+void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_inv_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV);
+        attr_set = true;
+    }
+    const size_t f_sy = (size_t)nx, f_sz = (size_t)nx * ny;
+    // compact reconstruction buffers: C1 = (n/2)^3, C2 = (n/4)^3, C3 = (n/8)^3, laid out as in the forward pass
+    double* cbuf[4] = {nullptr, lowbuf, nullptr, nullptr};
+    cbuf[2] = cbuf[1] + (size_t)(nx >> 1) * (ny >> 1) * (nz >> 1);
+    cbuf[3] = cbuf[2] + (size_t)(nx >> 2) * (ny >> 2) * (nz >> 2);
+    for (int l = 3; l >= 0; l--) {
+        const int n1 = nx >> l, n2 = ny >> l, n3 = nz >> l;
+        const int m1 = n1 / 2, m2 = n2 / 2, m3 = n3 / 2;
+        const double* lo;
+        size_t lo_sy, lo_sz;
+        if (l == 3) { lo = src; lo_sy = f_sy; lo_sz = f_sz; }
+        else { lo = cbuf[l + 1]; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
+        double* o;
+        size_t o_sy, o_sz;
+        if (l == 0) { o = dst; o_sy = f_sy; o_sz = f_sz; }
+        else { o = cbuf[l]; o_sy = (size_t)n1; o_sz = (size_t)n1 * n2; }
+        const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
+        const int zps = pick_zps(tiles, m3);
+        dim3 grid(tiles, (m3 + zps - 1) / zps);
+        hipLaunchKernelGGL(k_inv_fused, grid, dim3(NTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
+                           n2, n3, zps);
+    }
+}
 
 }  // namespace wrk
