@@ -36,6 +36,9 @@ constexpr double kWavAccCoef = 1.75;
 constexpr unsigned long kSafetyBufferFactor = 1;
 
 thread_local std::string g_err;
+// Device phases of different contexts are serialised (they are tens of milliseconds); what
+// overlaps between concurrent encode/decode calls is the host range coding and the copies.
+std::mutex g_gpu_phase;
 int g_verbose = -1;  // -1: not initialised from the environment yet
 int g_threads = WR_NLAYMAX;
 
@@ -607,7 +610,11 @@ int wr_encode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtfla
         });
         return WR_OK;
     };
-    int rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, tolrel, c->d_planes, info, &local, on_plane);
+    int rc;
+    {
+        std::lock_guard<std::mutex> gpu(g_gpu_phase);
+        rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, tolrel, c->d_planes, info, &local, on_plane);
+    }
     t_gpu_done = now();
     for (auto& w : workers) w.join();
     if (rc) return rc;
@@ -698,9 +705,12 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     memset(&p, 0, sizeof p);
     p.nlay = nlay;
     for (int l = 0; l < nlay; l++) { p.q[l] = c->d_planes + l * pitch; p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; }
-    if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> gpu(g_gpu_phase);
+        if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); local.quant_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_b, c->ev_c)); local.transform_ms = ms;

@@ -89,13 +89,27 @@ struct SymEntry {
 template <uint32_t TOT>
 inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry* tab, uint32_t top_sym)
 {
+    // The renormalisation test is data dependent and badly predicted, so the common case (at
+    // most one byte shifted out per symbol) is written branch-free: the byte is stored
+    // unconditionally and `pos` advances by 0 or 1.  Two rare cases keep a branch: a pending
+    // carry at the moment a byte leaves, and a second shift (symbol probability < 1/256).
     uint32_t low = e.low, range = e.range, nbytes = e.nbytes;
     uint8_t* out = e.out;
     size_t pos = e.pos;
     const uint32_t tot = TOT ? TOT : bs;
     for (uint32_t i = 0; i < bs; i++) {
         const uint32_t c = s[i];
-        while (range <= kBottom) {
+        const uint32_t sh = range <= kBottom;  // 0 or 1
+        if (__builtin_expect(sh & (low >> 31), 0)) {
+            size_t p = pos - 1;
+            while (++out[p] == 0) p--;
+        }
+        out[pos] = (uint8_t)(low >> kShift);
+        pos += sh;
+        nbytes += sh;
+        low = sh ? (low << 8) & (kTop - 1) : low;
+        range = sh ? range << 8 : range;
+        while (__builtin_expect(range <= kBottom, 0)) {
             if (low & kTop) {
                 size_t p = pos - 1;
                 while (++out[p] == 0) p--;
@@ -219,14 +233,24 @@ inline size_t decode_symbols(Dec& d, uint8_t* dst, size_t room, uint32_t bs, con
     const uint32_t tot = TOT ? TOT : bs;
     const uint32_t nout = bs < room ? bs : (uint32_t)room;
     uint32_t low = d.low, range = d.range;
-    uint8_t held = d.held;
+    uint32_t held = d.held;
     const uint8_t* in = d.in;
     size_t pos = d.pos;
     const size_t len = d.len;
-    uint32_t i = 0;
-    for (; i < bs; i++) {
-        while (range <= kBottom) {
-            low = (low << 8) | (((uint32_t)held << kExtra) & 0xff);
+    for (uint32_t i = 0; i < bs; i++) {
+        // first renormalisation step branch-free (see encode_symbols); the input byte is read
+        // speculatively, which needs one readable byte at in[pos]: guaranteed while pos < len
+        if (__builtin_expect(pos < len, 1)) {
+            const uint32_t sh = range <= kBottom;
+            const uint32_t nb = in[pos];
+            const uint32_t l2 = (low << 8) | ((held << kExtra) & 0xff) | (nb >> (8 - kExtra));
+            low = sh ? l2 : low;
+            held = sh ? nb : held;
+            range = sh ? range << 8 : range;
+            pos += sh;
+        }
+        while (__builtin_expect(range <= kBottom, 0)) {
+            low = (low << 8) | ((held << kExtra) & 0xff);
             held = pos < len ? in[pos] : 0;
             pos++;
             low |= held >> (8 - kExtra);
@@ -241,7 +265,7 @@ inline size_t decode_symbols(Dec& d, uint8_t* dst, size_t room, uint32_t bs, con
         range = (c != top_sym) ? help * tab[c].sy : range - t;
         if (i < nout) dst[i] = (uint8_t)c;
     }
-    d.low = low; d.range = range; d.held = held; d.pos = pos;
+    d.low = low; d.range = range; d.held = (uint8_t)held; d.pos = pos;
     return bs;
 }
 
