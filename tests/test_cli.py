@@ -68,3 +68,30 @@ def test_reference_cli_on_our_library(case, golden_cli):
     if not (os.path.exists(enc) and os.path.exists(dec)):
         pytest.skip("oracle/_ref/*_ref_dyn not built")
     run_case(case, enc, dec, golden_cli[case])
+
+
+@pytest.mark.gpu
+def test_sharded_driver_with_gpu_codec(golden_cli):
+    """waverange_amd.sharded with the product codec (Context.encode), single process."""
+    import numpy as np
+    from waverange_amd import api, sharded
+    api.set_verbosity(0)
+    case = "inmeta_new_type0"
+    c = cli_cases.CASES[case]
+    specs = []
+    for fd in c["fields"]:
+        nbytes, nx, ny, nz, nh, idinv = fd["spec"]
+        specs.append(dict(nbytes=nbytes, nx=nx, ny=ny, nz=nz, nh=nh, idinv=idinv, icomp=fd["icomp"], tol_base=float(fd["tol"])))
+    with api.Context(0) as ctx:
+        def codec(fld, tol):
+            buf = ctx.to_device(fld)
+            enc, _ = ctx.encode(buf, fld.shape, tol)
+            enc["data"] = enc["data"].copy()
+            buf.free()
+            return enc
+        with tempfile.TemporaryDirectory() as d:
+            cli_cases.write_inputs(case, d)
+            sharded.wrenc_sharded(os.path.join(d, "data.bin"), os.path.join(d, "data.wrb"), os.path.join(d, "data.wrh"),
+                                  specs, c["file_type"], bool(c["flip"]), codec)
+            assert open(os.path.join(d, "data.wrh")).read() == golden_cli[case]["wrh"]
+            assert sha_file(os.path.join(d, "data.wrb")) == golden_cli[case]["wrb_sha256"]

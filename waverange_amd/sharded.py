@@ -1,0 +1,134 @@
+"""Field sharding across GPUs: independent fields, one process per GPU, no
+data-path collective -- only a gather of the coded fields to rank 0, which writes the
+`.wrh` / `.wrb` pair in field order (the container of reference src/generic/gen_aux.cpp).
+
+The codec is passed in (``codec(field_zyx, tolrel) -> dict`` with the outputs of
+``encoding_wrap``): on a GPU node it is ``Context.encode`` of waverange_amd.api; the CPU tests
+inject another one to exercise the plan / gather / container logic under gloo.
+"""
+import struct
+
+import numpy as np
+
+CODER_VERSION = 31503  # reference src/core/defs.h:34
+
+
+def plan(nf, world):
+    """Round-robin field -> rank assignment: rank r codes fields r, r+world, ..."""
+    return [list(range(r, nf, world)) for r in range(world)]
+
+
+def field_offsets(specs, file_type):
+    """Byte offset of every field record in a generic input file.
+    specs: list of dicts with nbytes, nx, ny, nz, nh (reference gen_aux.cpp:230-397)."""
+    ml = 4 if file_type == 0 else (8 if file_type == 1 else 0)
+    offs, pos = [], 0
+    for s in specs:
+        offs.append(pos)
+        pos += 2 * ml + s["nbytes"] * s["nx"] * s["ny"] * s["nz"] * s["nh"]
+    return offs
+
+
+def read_field(path, offset, spec, file_type, flip):
+    """One field as float64 (nz*nh, ny, nx) + its 8 record-marker bytes (gen_aux.cpp:230-397)."""
+    ml = 4 if file_type == 0 else (8 if file_type == 1 else 0)
+    n = spec["nx"] * spec["ny"] * spec["nz"] * spec["nh"]
+    recl = bytearray(8)
+    with open(path, "rb") as fh:
+        fh.seek(offset)
+        if ml:
+            m = fh.read(ml)
+            recl[:ml] = m[::-1] if flip else m
+        dt = np.dtype("f4" if spec["nbytes"] == 4 else "f8").newbyteorder(">" if flip else "<")
+        a = np.frombuffer(fh.read(n * spec["nbytes"]), dtype=dt).astype(np.float64)
+    if spec.get("idinv", 0):  # file loops ix outermost ... ih innermost
+        a = a.reshape(spec["nx"], spec["ny"], spec["nz"], spec["nh"]).transpose(3, 2, 1, 0)
+    return np.ascontiguousarray(a).reshape(spec["nz"] * spec["nh"], spec["ny"], spec["nx"]), bytes(recl)
+
+
+def encode_my_fields(path, specs, file_type, flip, my_ids, codec, effective_tol):
+    """Code the fields of this rank.  Returns {field id: record} with record = dict(recl, enc)
+    (enc is None for fields stored uncompressed, then `raw` holds their bytes)."""
+    offs = field_offsets(specs, file_type)
+    out = {}
+    for i in my_ids:
+        fld, recl = read_field(path, offs[i], specs[i], file_type, flip)
+        if specs[i].get("icomp", 1):
+            enc = codec(fld, effective_tol)
+            out[i] = dict(recl=recl, enc={k: enc[k] for k in ("tolabs", "midval", "halfspanval", "wlev", "nlay",
+                                                              "ntot_enc", "deps_vec", "minval_vec", "len_enc_vec")},
+                          payload=bytes(np.ascontiguousarray(enc["data"][:enc["ntot_enc"]])))
+        else:
+            dt = "<f4" if specs[i]["nbytes"] == 4 else "<f8"
+            out[i] = dict(recl=recl, enc=None, payload=fld.astype(dt).tobytes())
+    return out
+
+
+def gather_fields(mine, nf, dist=None):
+    """All coded fields on rank 0 in field order (None elsewhere).  `dist` is torch.distributed
+    (already initialised) or None for a single process."""
+    if dist is None or dist.get_world_size() == 1:
+        return [mine[i] for i in range(nf)]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(mine, bucket, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return [merged[i] for i in range(nf)]
+
+
+def _g19(v):
+    return "%.19g" % v  # 19 significant digits, reference gen_aux.cpp:532 (quirk Q4)
+
+
+def write_container(wrh_path, wrb_path, wrb_name, specs, file_type, flip, records):
+    """`.wrh` text + `.wrb` payloads exactly as the reference writes them
+    (gen_enc.cpp:509-520, gen_aux.cpp:401-408, 419-468, 505-556), including quirk Q2."""
+    lines = [" ===== Header file for compressed data =====", " Coder version: %d" % CODER_VERSION,
+             " Encoded data file name: %s" % wrb_name,
+             " File type (0: Fortran sequential w 4-byte recl; 1: Fortran sequential w 8-byte recl; 2: C/C++): %d" % file_type,
+             " Converted big endian to little endian or vice versa" if flip else " No endian conversion",
+             " Number of fields in the file, nf: %d" % len(specs)]
+    prev_ntot = 0
+    with open(wrb_path, "wb") as wrb:
+        for i, (s, r) in enumerate(zip(specs, records)):
+            e = r["enc"]
+            icomp = 1 if e is not None else 0
+            reminder = e["ntot_enc"] if icomp else prev_ntot
+            head = " nbytes; recl; nx; ny; nz; nh; idinv; icomp;"
+            if icomp:
+                head += " tol_base; tolabs; midval; halfspanval; wlev; nlay; ntot_enc;"
+            if reminder > 0:
+                head += " deps_vec(1:nlay); minval_vec(1:nlay); len_enc_vec(1:nlay)"
+            lines += [" -----", str(i), head, str(s["nbytes"]),
+                      "".join("%x " % b for b in r["recl"]), str(s["nx"]), str(s["ny"]), str(s["nz"]), str(s["nh"]),
+                      str(s.get("idinv", 0)), str(icomp)]
+            if icomp:
+                lines += [_g19(s["tol_base"]), _g19(e["tolabs"]), _g19(e["midval"]), _g19(e["halfspanval"]),
+                          str(e["wlev"]), str(e["nlay"]), str(e["ntot_enc"])]
+                if e["ntot_enc"] > 0:
+                    lines += ["".join(_g19(v) + " " for v in e["deps_vec"]),
+                              "".join(_g19(v) + " " for v in e["minval_vec"]),
+                              "".join("%d " % v for v in e["len_enc_vec"])]
+                prev_ntot = e["ntot_enc"]
+            wrb.write(r["payload"])
+    with open(wrh_path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def wrenc_sharded(in_path, wrb_path, wrh_path, specs, file_type, flip, codec, dist=None):
+    """Sharded generic encoder: every rank codes its fields, rank 0 writes the container.
+    Quirk Q1 of the reference CLI is kept: the tolerance of the LAST field is applied to all."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    eff_tol = specs[-1]["tol_base"]
+    mine = encode_my_fields(in_path, specs, file_type, flip, plan(len(specs), world)[rank], codec, eff_tol)
+    records = gather_fields(mine, len(specs), dist)
+    if rank == 0:
+        import os
+        write_container(wrh_path, wrb_path, os.path.basename(wrb_path), specs, file_type, flip, records)
+    if dist is not None and world > 1:
+        dist.barrier()
