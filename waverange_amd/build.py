@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
         os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
         for s in SOURCES:
             o = os.path.join(HERE, "build", s.replace("/", "_") + ".o")
-            cmd = [hipcc] + COMMON + ["-c", os.path.join(CSRC, s), "-o", o]
+            cmd = [hipcc] + COMMON + os.environ.get("WR_CXXFLAGS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

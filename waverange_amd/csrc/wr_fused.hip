@@ -37,11 +37,14 @@ namespace wrk {
 namespace {
 
 constexpr int TXP = 64;             // x-pairs per tile
-constexpr int TYP = 16;             // y-pairs per tile
+#ifndef WR_FTYP
+#define WR_FTYP 16
+#endif
+constexpr int TYP = WR_FTYP;        // y-pairs per tile
 constexpr int RX = TXP + 4;         // raw pairs per staged row: 2 + 64 + 2
 constexpr int RROWS = 2 * TYP + 7;  // staged rows: 4 + 32 + 3
 constexpr int NCHUNK = RROWS * RX;  // 16-byte chunks per plane (2652)
-constexpr int NTHR = 512;
+constexpr int NTHR = 32 * TYP;      // one thread = one x-pair x two y-pairs
 constexpr int NWAVE = NTHR / 64;
 constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (3)
 constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * 2 * TXP * 8;
@@ -94,7 +97,7 @@ __device__ inline void lift_fwd_two(const double s[6], const double d[5], double
 
 }  // namespace
 
-__global__ __launch_bounds__(NTHR) void k_fwd_fused(
+__global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const double* __restrict__ src, size_t s_sy, size_t s_sz,  // level input (x stride 1)
     double* __restrict__ dst, size_t d_sy, size_t d_sz,        // coefficient array (final positions)
     double* __restrict__ low, size_t l_sy, size_t l_sz,        // low-pass octant destination
@@ -254,12 +257,18 @@ __global__ __launch_bounds__(NTHR) void k_fwd_fused(
 //     pointwise z and y steps), then every lane rebuilds one x-pair per row and stores 16 B.
 // =====================================================================================
 namespace {
+#ifndef WR_ITYP
+#define WR_ITYP 16
+#endif
+constexpr int ITYP = WR_ITYP;
+constexpr int INTHR = 32 * ITYP;
+constexpr int INWAVE = INTHR / 64;
 constexpr int HX = TXP + 4;              // coefficient columns per quadrant row (68)
-constexpr int HY = TYP + 4;              // coefficient rows per quadrant (20)
+constexpr int HY = ITYP + 4;              // coefficient rows per quadrant (20)
 constexpr int CROW = HX / 2;             // 16-byte chunks per row (34)
 constexpr int NCI = 4 * HY * CROW;       // chunks per plane (2720)
-constexpr int KCI = (NCI + NTHR - 1) / NTHR;  // chunk slots per thread (6)
-constexpr size_t LDS_INV = (size_t)3 * NCI * 16 + (size_t)NWAVE * 2 * (2 * HX) * 8;
+constexpr int KCI = (NCI + INTHR - 1) / INTHR;  // chunk slots per thread (6)
+constexpr size_t LDS_INV = (size_t)3 * NCI * 16 + (size_t)INWAVE * 2 * (2 * HX) * 8;
 
 // whole-sample symmetric extension in coefficient space (even length 2M):
 //   low-pass  s[-k] = s[k],    s[M-1+k] = s[M-k]
@@ -310,7 +319,7 @@ __device__ inline void lift_inv_two(const double sr[5], const double dr[6], doub
 }
 }  // namespace
 
-__global__ __launch_bounds__(NTHR) void k_inv_fused(
+__global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     const double* __restrict__ src, size_t s_sy, size_t s_sz,  // coefficient array (detail octants)
     const double* __restrict__ low, size_t l_sy, size_t l_sz,  // low-pass octant (previous level's output)
     double* __restrict__ out, size_t o_sy, size_t o_sz,        // reconstructed box of this level
@@ -319,11 +328,11 @@ __global__ __launch_bounds__(NTHR) void k_inv_fused(
     extern __shared__ double2 lds2[];
     double2* in = lds2;                   // [2][NCI]   staged low-z / high-z coefficient planes
     double2* zb = lds2 + 2 * NCI;         // [NCI]      one z-reconstructed plane
-    double* yb = reinterpret_cast<double*>(lds2 + 3 * NCI);  // [NWAVE][2][2*HX] wave-private rows
+    double* yb = reinterpret_cast<double*>(lds2 + 3 * NCI);  // [INWAVE][2][2*HX] wave-private rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + TXP - 1) / TXP;
-    const int px0 = (blockIdx.x % tiles_x) * TXP, py0 = (blockIdx.x / tiles_x) * TYP;
+    const int px0 = (blockIdx.x % tiles_x) * TXP, py0 = (blockIdx.x / tiles_x) * ITYP;
     const int z0 = blockIdx.y * zps;
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(NTHR) void k_inv_fused(
     unsigned lll_mask = 0;
 #pragma unroll
     for (int k = 0; k < KCI; k++) {
-        const int c = tid + NTHR * k;
+        const int c = tid + INTHR * k;
         const int q = c / (HY * CROW), rem = c - q * (HY * CROW);
         const int row = rem / CROW, cc = rem - row * CROW;
         const int gyp = (q & 2) ? mirror_d(py0 - 2 + row, m2) : mirror_s(py0 - 2 + row, m2);
@@ -350,8 +359,8 @@ __global__ __launch_bounds__(NTHR) void k_inv_fused(
         const double* ph = src + (size_t)(m3 + t) * s_sz;  // high-z plane
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
-            if (tid + NTHR * k < NCI) {
-                double2* l0 = in + NTHR * k + (w << 6);
+            if (tid + INTHR * k < NCI) {
+                double2* l0 = in + INTHR * k + (w << 6);
                 const double* gl = ((lll_mask >> k) & 1) ? pll + offL[k] : pl + offL[k];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
                                                  (__attribute__((address_space(3))) void*)l0, 16, 0, 0);
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(NTHR) void k_inv_fused(
         // ---- z step on every staged point  (waveletcdf97_3d.c:312-337 along z)
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
-            const int c = tid + NTHR * k;
+            const int c = tid + INTHR * k;
             if (c < NCI) {
                 double lo[2] = {0, 0}, hi[2] = {0, 0};
                 if (t < m3) {
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(NTHR) void k_inv_fused(
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < KCI; k++)
-                if (tid + NTHR * k < NCI) zb[tid + NTHR * k] = odd[k];
+                if (tid + INTHR * k < NCI) zb[tid + INTHR * k] = odd[k];
             __syncthreads();
             yxstage(2 * j + 1);
         }
@@ -501,7 +510,7 @@ size_t fused_lowbuf_elems(int nx, int ny, int nz)
     return tot + 64;
 }
 
-static int pick_zps(int tiles, int m3)
+static int pick_zps(int tiles, int m3, int per_round)
 {
     // One workgroup is resident per CU (LDS), so the grid should be a small whole number of
     // rounds of 256 workgroups; every segment pays 4 extra steps (2 warm-up + 2 drain).
@@ -514,7 +523,7 @@ static int pick_zps(int tiles, int m3)
         const int zps = (m3 + segs - 1) / segs;
         if (zps < 4) break;
         const long long wgs = (long long)tiles * ((m3 + zps - 1) / zps);
-        const long long rounds = (wgs + 255) / 256;
+        const long long rounds = (wgs + per_round - 1) / per_round;
         const double cost = (double)rounds * (zps + 4);  // steps on the critical path
         if (cost < best_cost - 1e-9) { best_cost = cost; best = zps; }
     }
@@ -540,7 +549,7 @@ void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx,
         if (l < 3) { lo = lb; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
         else { lo = dst; lo_sy = d_sy; lo_sz = d_sz; }
         const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
-        const int zps = pick_zps(tiles, m3);
+        const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_BYTES));
         dim3 grid(tiles, (m3 + zps - 1) / zps);
         hipLaunchKernelGGL(k_fwd_fused, grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
                            lo_sz, n1, n2, n3, zps);
@@ -572,10 +581,10 @@ void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx,
         size_t o_sy, o_sz;
         if (l == 0) { o = dst; o_sy = f_sy; o_sz = f_sz; }
         else { o = cbuf[l]; o_sy = (size_t)n1; o_sz = (size_t)n1 * n2; }
-        const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
-        const int zps = pick_zps(tiles, m3);
+        const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + ITYP - 1) / ITYP);
+        const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_INV));
         dim3 grid(tiles, (m3 + zps - 1) / zps);
-        hipLaunchKernelGGL(k_inv_fused, grid, dim3(NTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
+        hipLaunchKernelGGL(k_inv_fused, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
                            n2, n3, zps);
     }
 }
