@@ -34,6 +34,22 @@ def box_elems(n, levels=4):
     return tot
 
 
+def measured_traffic(n):
+    """HBM bytes per transform from the committed PMC passes (profiles/rNN/traffic_<n>.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), mean of forward and inverse; None if not measured."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%d.json" % n))):
+        try:
+            with open(f) as fh:
+                t = json.load(fh)
+            best = 0.5 * (t["fwd"]["total_bytes"] + t["inv"]["total_bytes"])
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(size, tols):
     """The reference itself (oracle/_ref, kind "reference") or, if absent, the oracle port,
     single thread, on a bounded sample of the same workload."""
@@ -86,10 +102,21 @@ def main():
 
     import torch
     dist = None
+    # WR_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then
+    # share devices and the barrier runs on CPU tensors); the real multi-GPU run uses RCCL.
+    backend = os.environ.get("WR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (libwaverange_amd has no CPU fallback)")
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     import numpy as np
     from waverange_amd import api
     api.set_verbosity(0)
@@ -100,7 +127,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            t = torch.zeros(1, device="cuda")
+            t = torch.zeros(1, device=red_dev)
             dist.all_reduce(t)
             torch.cuda.synchronize()
 
@@ -108,7 +135,7 @@ def main():
     # independent jobs and run concurrently on the one GPU; their device phases serialise inside
     # the library, their host range coding overlaps
     import threading
-    ctx = api.Context(local_rank)
+    ctx = api.Context(dev_index)
     shape = (n, n, n)
     nelem = n ** 3
     orig = ctx.alloc(nelem * 8)
@@ -117,7 +144,7 @@ def main():
     _, cap = api.setup_wr(n, n, n)
     lanes = []
     for i, tol in enumerate(tols):
-        c = ctx if i == 0 else api.Context(local_rank)
+        c = ctx if i == 0 else api.Context(dev_index)
         lanes.append(dict(tol=tol, ctx=c, work=c.alloc(nelem * 8), data=np.empty(cap, dtype=np.uint8)))
 
     stats = {t: {} for t in tols}
@@ -162,7 +189,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -189,7 +216,7 @@ def main():
                        "concurrent_jobs_per_gpu": len(tols),
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(n),
                          "kernel": "3-D CDF-9/7 transform, 4 levels (mean of forward and inverse), all launches",
                          "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3)},
             "stages": {"encode_s": round(mean(acc["enc_s"]), 3), "decode_s": round(mean(acc["dec_s"]), 3),

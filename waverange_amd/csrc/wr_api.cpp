@@ -614,6 +614,9 @@ int wr_encode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtfla
     {
         std::lock_guard<std::mutex> gpu(g_gpu_phase);
         rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, tolrel, c->d_planes, info, &local, on_plane);
+        // plane D2H copies run as blit kernels on this image: keep other contexts' kernels off the
+        // device until they are through (tens of ms; the coder threads start per plane regardless)
+        (void)hipStreamSynchronize(c->copy);
     }
     t_gpu_done = now();
     for (auto& w : workers) w.join();
@@ -679,18 +682,11 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     int bad = -1;
     for (int l = 0; l < nlay; l++) {
         workers[l].join();
-        if (got[l] != n) { bad = l; continue; }
-        // plane l: pinned host -> device as soon as its decoder thread is done
-        hipError_t e = hipMemcpyAsync(c->d_planes + l * pitch, c->h_planes + l * pitch, n, hipMemcpyHostToDevice, c->copy);
-        if (e == hipSuccess) e = hipEventRecord(c->ev_copy[l], c->copy);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_copy[l], 0);
-        if (e != hipSuccess) { bad = l; g_err = hipGetErrorString(e); }
+        if (got[l] != n) bad = l;
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
     }
-    if (bad >= 0) {
-        (void)hipStreamSynchronize(c->copy);
+    if (bad >= 0)
         return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
-    }
     const double t_coded = now();
     if (verbose()) {  // wrappers.cpp:489, 503-510
         for (int l = 0; l < nlay; l++) {
@@ -707,6 +703,8 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     for (int l = 0; l < nlay; l++) { p.q[l] = c->d_planes + l * pitch; p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; }
     {
         std::lock_guard<std::mutex> gpu(g_gpu_phase);
+        for (int l = 0; l < nlay; l++)  // planes: pinned host -> device
+            HIPCHK(hipMemcpyAsync(c->d_planes + l * pitch, c->h_planes + l * pitch, n, hipMemcpyHostToDevice, c->stream));
         if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
