@@ -37,9 +37,8 @@ void setup_wr(int nx, int ny, int nz, unsigned char *nlaymax, unsigned long *nto
 
 /* replaces encoding_wrap, reference src/core/wrappers.cpp:228-452 (wrappers.h:53).
  * fld_1d: host double[nx*ny*nz], x fastest.  data_enc: host buffer of ntot_enc_max bytes.
- * Only the uniform cutoff (mx*my*mz == 1; what every reference CLI passes) is implemented
- * on the GPU; mx*my*mz > 1 is a fatal error.  Unlike the reference, fld_1d is left
- * untouched unless WR_WRITEBACK_RESIDUAL=1 is set in the environment. */
+ * mx*my*mz > 1 selects the reference's non-uniform (local) cutoff branch, wrappers.cpp:343-379.
+ * Unlike the reference, fld_1d is left untouched unless WR_WRITEBACK_RESIDUAL=1 is set. */
 void encoding_wrap(int nx, int ny, int nz, double *fld_1d, int wtflag, int mx, int my, int mz,
                    double *cutoffvec, double *tolabs, double *midval, double *halfspanval,
                    unsigned char *wlev, unsigned char *nlay, unsigned long *ntot_enc,
@@ -65,6 +64,36 @@ void decoding_wrap_f(int *nx, int *ny, int *nz, double *fld, double *midval, dou
 /* replaces waveletcdf97_3d, reference src/waveletcdf97_3d/waveletcdf97_3d.c:38 (exported by
  * the reference's .so; host buffer, in place; lvl>0 forward, lvl<0 inverse) */
 void waveletcdf97_3d(int n1, int n2, int n3, int lvl, double *x);
+
+/* Part 1b: the other symbols the reference's .so exports (host-only integer code) */
+/* rangecoder state, layout of reference src/rangecod/rangecod.h:110-131 */
+typedef struct {
+    unsigned int low, range, help;
+    unsigned char buffer;
+    unsigned int bytecount;
+    unsigned char *databuf;
+    unsigned long datalen, datapos;
+} rangecoder;
+extern char coderversion[];
+/* replace the rngcod13 primitives of reference src/rangecod/rangecod.c:170-404 */
+void start_encoding(rangecoder *rc, char c, unsigned long initlength);
+void encode_freq(rangecoder *rc, unsigned int sy_f, unsigned int lt_f, unsigned int tot_f);
+void encode_shift(rangecoder *rc, unsigned int sy_f, unsigned int lt_f, unsigned int shift);
+unsigned int done_encoding(rangecoder *rc);
+int start_decoding(rangecoder *rc);
+unsigned int decode_culfreq(rangecoder *rc, unsigned int tot_f);
+unsigned int decode_culshift(rangecoder *rc, unsigned int shift);
+void decode_update(rangecoder *rc, unsigned int sy_f, unsigned int lt_f, unsigned int tot_f);
+unsigned char decode_byte(rangecoder *rc);
+unsigned short decode_short(rangecoder *rc);
+void done_decoding(rangecoder *rc);
+void init_databuf(rangecoder *rc, unsigned long maxlen);
+void free_databuf(rangecoder *rc);
+void countblock(int *buffer, unsigned int length, unsigned int *counters);
+void readcounts(rangecoder *rc, unsigned int *counters);
+/* replaces ind_p2w_3d, reference src/waveletcdf97_3d/waveletcdf97_3d.c:473-553 */
+void ind_p2w_3d(int lvlin, int n1, int n2, int n3, int i1in, int i2in, int i3in, int *lvl, int *i1,
+                int *i2, int *i3);
 
 /* ----------------------------------------------------------------------------------- */
 /* Part 2: device-resident API                                                          */
@@ -159,6 +188,10 @@ int wr_dev_decode_planes(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz,
 int wr_encode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtflag,
                      double tolrel, wr_enc_info *info, unsigned char *data_enc, size_t cap,
                      wr_timings *tm);
+/* same with the reference's local cutoff vector (mx*my*mz entries, host memory) */
+int wr_encode_device_local(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtflag, int mx,
+                           int my, int mz, const double *cutoffvec, wr_enc_info *info,
+                           unsigned char *data_enc, size_t cap, wr_timings *tm);
 int wr_decode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz,
                      const wr_enc_info *info, const unsigned char *data_enc, wr_timings *tm);
 

@@ -262,3 +262,22 @@ def test_large_roundtrip_properties(ctx, oracle):
     linf = np.abs(rec - orig).max() / np.abs(orig).max()
     assert linf < 1.05e-5, linf     # the reference itself may exceed tol by ~1 %
     buf.free()
+
+
+@pytest.mark.parametrize("shape,m", [((32, 16, 8), (2, 2, 2)), ((64, 64, 64), (4, 2, 1)), ((37, 21, 13), (3, 2, 2))])
+def test_local_cutoff_branch(ctx, oracle, shape, m):
+    """mx*my*mz > 1: the reference's non-uniform cutoff (wrappers.cpp:343-379) on the GPU."""
+    nx, ny, nz = shape
+    f = synth.field(nx, ny, nz, seed=77)
+    rs = np.random.RandomState(3)
+    cut = 10.0 ** rs.uniform(-6, -2, size=m[0] * m[1] * m[2])
+    want = oracle.encode(f, None, cutoff=list(cut), m=m)
+    buf = ctx.to_device(f)
+    enc, _ = ctx.encode_local(buf, f.shape, cut, m)
+    for k in ("tolabs", "midval", "halfspanval", "wlev", "nlay", "ntot_enc", "len_enc_vec"):
+        assert enc[k] == want[k], k
+    assert bits_equal(enc["deps_vec"], want["deps_vec"]) and bits_equal(enc["minval_vec"], want["minval_vec"])
+    assert np.array_equal(enc["data"], want["data"])
+    ctx.decode(buf, f.shape, enc)
+    assert bits_equal(buf.download(np.float64, f.size), oracle.decode(want, f.shape))
+    buf.free()

@@ -95,3 +95,77 @@ def test_no_gpu_fails_loudly(api):
         pytest.skip("a GPU is present")
     with pytest.raises(api.WaveRangeError):
         api.Context(0)
+
+
+def test_reference_export_set_is_complete(api):
+    """The 24 unmangled symbols the reference's libwaverange.so exports (nm -D)."""
+    want = {"setup_wr", "encoding_wrap", "decoding_wrap", "setup_wr_f", "encoding_wrap_f", "decoding_wrap_f",
+            "waveletcdf97_3d", "ind_p2w_3d", "start_encoding", "encode_freq", "encode_shift", "done_encoding",
+            "start_decoding", "decode_culfreq", "decode_culshift", "decode_update", "decode_byte", "decode_short",
+            "done_decoding", "init_databuf", "free_databuf", "countblock", "readcounts", "coderversion"}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH]).decode()
+    have = set(line.split()[-1] for line in out.splitlines())
+    assert want <= have, want - have
+    refso = os.path.join(ROOT, "oracle", "_ref", "libwaverange_ref.so")
+    if os.path.exists(refso):
+        r = subprocess.check_output(["nm", "-D", "--defined-only", refso]).decode()
+        ref_syms = set(line.split()[-1] for line in r.splitlines() if line.split()[-2] in "TBD")
+        assert {s for s in ref_syms if not s.startswith("_")} <= have
+
+
+def test_rngcod13_primitives_and_index_map(api, oracle, golden):
+    """Part 1b symbols: drive the exported primitives with the reference's block model
+    (wrappers.cpp:68-149) and compare with the oracle's stream; decode it back; ind_p2w_3d."""
+    import ctypes as C
+    L = api.lib()
+
+    class RC(C.Structure):
+        _fields_ = [("low", C.c_uint), ("range", C.c_uint), ("help", C.c_uint), ("buffer", C.c_ubyte),
+                    ("bytecount", C.c_uint), ("databuf", C.POINTER(C.c_ubyte)), ("datalen", C.c_ulong),
+                    ("datapos", C.c_ulong)]
+    for f in ("start_encoding", "encode_freq", "encode_shift", "init_databuf", "free_databuf", "decode_update"):
+        getattr(L, f).restype = None
+    L.start_encoding.argtypes = [C.POINTER(RC), C.c_char, C.c_ulong]
+    L.encode_freq.argtypes = L.encode_shift.argtypes = L.decode_update.argtypes = [C.POINTER(RC)] + [C.c_uint] * 3
+    L.done_encoding.argtypes = L.start_decoding.argtypes = L.done_decoding.argtypes = [C.POINTER(RC)]
+    L.init_databuf.argtypes = [C.POINTER(RC), C.c_ulong]
+    L.free_databuf.argtypes = [C.POINTER(RC)]
+    L.decode_culfreq.argtypes = [C.POINTER(RC), C.c_uint]
+    L.decode_culfreq.restype = C.c_uint
+    L.decode_short.argtypes = [C.POINTER(RC)]
+    L.decode_short.restype = C.c_ushort
+    p = kat_plane("skewed", 1000)
+    rc = RC()
+    L.init_databuf(C.byref(rc), 4096)
+    L.start_encoding(C.byref(rc), b"\x00", 0)
+    L.encode_freq(C.byref(rc), 1, 1, 2)
+    counts = np.bincount(p, minlength=256)
+    for c in counts:
+        L.encode_shift(C.byref(rc), 1, int(c), 16)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    for ch in p:
+        L.encode_freq(C.byref(rc), int(counts[ch]), int(cum[ch]), p.size)
+    L.encode_freq(C.byref(rc), 1, 0, 2)
+    L.done_encoding(C.byref(rc))
+    stream = bytes(rc.databuf[: rc.datapos])
+    assert stream.hex() == golden["G3"]["skewed_1000"]["stream_hex"]
+    # decode with the primitives
+    rc.datapos = 0
+    L.start_decoding(C.byref(rc))
+    assert L.decode_culfreq(C.byref(rc), 2) == 1
+    L.decode_update(C.byref(rc), 1, 1, 2)
+    got_counts = [L.decode_short(C.byref(rc)) for _ in range(256)]
+    assert got_counts == [int(c) for c in counts]
+    back = []
+    for _ in range(p.size):
+        cf = L.decode_culfreq(C.byref(rc), p.size)
+        s = int(np.searchsorted(cum, cf, side="right") - 1)
+        L.decode_update(C.byref(rc), int(counts[s]), int(cum[s]), p.size)
+        back.append(s)
+    assert back == [int(v) for v in p]
+    L.free_databuf(C.byref(rc))
+    L.ind_p2w_3d.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)] * 4
+    for n1, n2, n3, i1, i2, i3, l, w1, w2, w3 in golden["ind_p2w_3d"]:
+        o = [C.c_int() for _ in range(4)]
+        L.ind_p2w_3d(4, n1, n2, n3, i1, i2, i3, *[C.byref(v) for v in o])
+        assert tuple(v.value for v in o) == (l, w1, w2, w3)

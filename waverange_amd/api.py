@@ -98,6 +98,8 @@ def lib():
     L.wr_dev_decode_planes.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(EncInfo)]
     L.wr_encode_device.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                    C.POINTER(EncInfo), _vp, C.c_size_t, C.POINTER(Timings)]
+    L.wr_encode_device_local.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                                         C.POINTER(EncInfo), _vp, C.c_size_t, C.POINTER(Timings)]
     L.wr_decode_device.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(EncInfo), _vp,
                                    C.POINTER(Timings)]
     L.wr_range_encode_bound.restype = C.c_size_t
@@ -322,6 +324,20 @@ class Context:
                                       data.ctypes.data, data.size, C.byref(tm)))
         d = info.as_dict()
         d["data"] = data[:info.ntot_enc]
+        return d, tm.as_dict()
+
+    def encode_local(self, buf, shape, cutoff, m, wtflag=1):
+        """Encode with the reference's non-uniform cutoff: cutoff has mx*my*mz entries, m = (mx, my, mz)."""
+        nz, ny, nx = shape
+        _, cap = setup_wr(nx, ny, nz)
+        data = np.empty(cap, dtype=np.uint8)
+        cut = np.ascontiguousarray(cutoff, dtype=np.float64)
+        info, tm = EncInfo(), Timings()
+        _check(lib().wr_encode_device_local(self.h, buf.ptr, nx, ny, nz, wtflag, m[0], m[1], m[2],
+                                            cut.ctypes.data_as(_dp), C.byref(info), data.ctypes.data, data.size,
+                                            C.byref(tm)))
+        d = info.as_dict()
+        d["data"] = data[:info.ntot_enc].copy()
         return d, tm.as_dict()
 
     def decode(self, buf, shape, enc):

@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libwaverange_amd.so")
 ALIAS = os.path.join(HERE, "libwaverange.so")  # the reference's library name (drop-in link target)
 BIN = os.path.join(HERE, "bin")
 
-SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_rangecoder.cpp"]
+SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_rangecoder.cpp", "wr_compat.cpp"]
 CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"]}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
           "-Wno-unused-result", "-march=x86-64-v3"]

@@ -81,6 +81,7 @@ struct wr_ctx {
     uint8_t* d_planes = nullptr; size_t planes_bytes = 0;
     double* d_field = nullptr; size_t field_elems = 0;  // staging for the host-pointer API
     double* d_lowbuf = nullptr; size_t lowbuf_elems = 0;  // compact low-pass boxes (fused transform)
+    double* d_cutoff = nullptr; size_t cutoff_elems = 0;  // local cutoff vector (mx*my*mz > 1 only)
     double* d_partial = nullptr; double* d_result = nullptr;
     unsigned long long* d_idx = nullptr;
     // pinned host
@@ -322,7 +323,7 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy);
-    (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field); (void)hipFree(c->d_lowbuf);
+    (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field); (void)hipFree(c->d_lowbuf); (void)hipFree(c->d_cutoff);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
     (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_planes);
     for (int i = 0; i < WR_NLAYMAX; i++) { (void)hipEventDestroy(c->ev_plane[i]); (void)hipEventDestroy(c->ev_copy[i]); }
@@ -453,10 +454,30 @@ namespace {
 
 // Device part of the encoder.  on_plane(l, last) is called right after plane l's kernel has
 // been enqueued and ev_plane[l] recorded (the full pipeline hooks its D2H + coder thread in).
+// local cutoff description (mx*my*mz == 1: uniform cutoff, the benchmark path)
+struct Cutoff {
+    int mx = 1, my = 1, mz = 1;
+    const double* vec = nullptr;  // host, mx*my*mz entries
+    int count() const { return mx * my * mz; }
+};
+
 template <class OnPlane>
-int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, double tolrel,
+int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
                        uint8_t* d_planes, wr_enc_info* info, wr_timings* tm, OnPlane on_plane)
 {
+    // minimum cutoff = the global relative tolerance (wrappers.cpp:288-290)
+    double tolrel = cut.vec[0];
+    for (int k = 1; k < cut.count(); k++) if (cut.vec[k] < tolrel) tolrel = cut.vec[k];
+    const bool local = cut.count() > 1;
+    if (local) {
+        if (c->cutoff_elems < (size_t)cut.count()) {
+            if (c->d_cutoff) HIPCHK(hipFree(c->d_cutoff));
+            c->d_cutoff = nullptr; c->cutoff_elems = 0;
+            HIPCHK(hipMalloc(&c->d_cutoff, cut.count() * sizeof(double)));
+            c->cutoff_elems = cut.count();
+        }
+        HIPCHK(hipMemcpyAsync(c->d_cutoff, cut.vec, cut.count() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     const size_t n = (size_t)nx * ny * nz;
     const size_t pitch = wr_plane_pitch(n);
     if (int rc = ensure_scratch(c, n)) return rc;
@@ -494,6 +515,17 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
         if (verbose()) { printf("min=%g max=%g\n", lo, hi); printf("ilay=%u deps=%g\n", ilay, s.deps); }
         const bool resid = !s.last || c->keep_residual;
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
+        if (local) {
+            wrk::LocalCutoff lc;
+            lc.nx = nx; lc.ny = ny; lc.nz = nz; lc.wlev = info->wlev;
+            lc.mx = cut.mx; lc.my = cut.my; lc.mz = cut.mz;
+            lc.cutoff = c->d_cutoff;
+            lc.tol_scale = info->tolabs / tolrel;
+            lc.tolabs = info->tolabs;
+            lc.span = hi - lo;
+            wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, lc,
+                                      c->d_partial, c->d_result, c->stream);
+        } else
         wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, resid,
                             c->d_partial, c->d_result, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
@@ -527,7 +559,8 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     if ((uintptr_t)d_planes & 15) return fail(WR_ERR_ARG, "plane buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, tolrel, d_planes, info, nullptr,
+    Cutoff cut; cut.vec = &tolrel;
+    int rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, d_planes, info, nullptr,
                                 [](unsigned, bool) { return WR_OK; });
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -562,8 +595,27 @@ int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const
     return WR_OK;
 }
 
+static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
+                              wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm);
+
 int wr_encode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, double tolrel,
                      wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm)
+{
+    Cutoff cut; cut.vec = &tolrel;
+    return encode_device_impl(c, d_fld, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
+}
+
+int wr_encode_device_local(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, int mx, int my, int mz,
+                           const double* cutoffvec, wr_enc_info* info, unsigned char* data_enc, size_t cap,
+                           wr_timings* tm)
+{
+    if (mx < 1 || my < 1 || mz < 1 || !cutoffvec) return fail(WR_ERR_ARG, "bad local cutoff description");
+    Cutoff cut; cut.mx = mx; cut.my = my; cut.mz = mz; cut.vec = cutoffvec;
+    return encode_device_impl(c, d_fld, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
+}
+
+static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
+                              wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm)
 {
     if (int rc = ctx_bind(c)) return rc;
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
@@ -613,7 +665,7 @@ int wr_encode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtfla
     int rc;
     {
         std::lock_guard<std::mutex> gpu(g_gpu_phase);
-        rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, tolrel, c->d_planes, info, &local, on_plane);
+        rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, c->d_planes, info, &local, on_plane);
         // plane D2H copies run as blit kernels on this image: keep other contexts' kernels off the
         // device until they are through (tens of ms; the coder threads start per plane regardless)
         (void)hipStreamSynchronize(c->copy);
@@ -786,10 +838,7 @@ void encoding_wrap(int nx, int ny, int nz, double* fld_1d, int wtflag, int mx, i
                    unsigned long* ntot_enc, double* deps_vec, double* minval_vec, unsigned long* len_enc_vec,
                    unsigned char* data_enc)
 {
-    if (mx * my * mz != 1) {
-        g_err = "non-uniform cutoff (mx*my*mz > 1) is not implemented on the GPU path";
-        fatal("encoding_wrap");
-    }
+    if (mx < 1 || my < 1 || mz < 1) { g_err = "mx, my, mz must be >= 1"; fatal("encoding_wrap"); }
     wr_ctx* c = default_ctx();
     const size_t n = (size_t)nx * ny * nz;
     unsigned char nl; unsigned long cap;
@@ -798,7 +847,8 @@ void encoding_wrap(int nx, int ny, int nz, double* fld_1d, int wtflag, int mx, i
     wr_enc_info info;
     const bool wb = getenv("WR_WRITEBACK_RESIDUAL") && atoi(getenv("WR_WRITEBACK_RESIDUAL"));
     c->keep_residual = wb;
-    if (wr_encode_device(c, c->d_field, nx, ny, nz, wtflag, cutoffvec[0], &info, data_enc, cap, nullptr)) fatal("encoding_wrap");
+    if (wr_encode_device_local(c, c->d_field, nx, ny, nz, wtflag, mx, my, mz, cutoffvec, &info, data_enc, cap, nullptr))
+        fatal("encoding_wrap");
     if (wb && info.nlay && wr_dev_download(c, fld_1d, c->d_field, n * sizeof(double))) fatal("encoding_wrap");
     *tolabs = info.tolabs; *midval = info.midval; *halfspanval = info.halfspanval;
     *wlev = info.wlev; *nlay = info.nlay; *ntot_enc = info.ntot_enc;

@@ -29,6 +29,20 @@ void last_zero_index(const double* x, size_t n, unsigned long long* out, hipStre
 void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval,
                     uint8_t* q, bool write_resid, double* partial, double* result, hipStream_t st);
 
+// ---- quantizer plane with the non-uniform (local) cutoff mask (wrappers.cpp:343-379, 397-398):
+// loops over PHYSICAL positions, maps each to its wavelet-space index (ind_p2w_3d,
+// waveletcdf97_3d.c:473-553) and quantizes there; coefficients of the finest level whose plane
+// range is below the local precision are zeroed.  Residual update and its min/max are fused.
+struct LocalCutoff {
+    int nx, ny, nz, wlev;
+    int mx, my, mz;
+    const double* cutoff;  // device array, mx*my*mz entries
+    double tol_scale;      // tolabs / tolrel
+    double tolabs, span;   // span = maxval - minval of the plane
+};
+void quantize_plane_local(double* x, size_t n, double aopt, double bopt, double deps, double minval,
+                          uint8_t* q, const LocalCutoff& lc, double* partial, double* result, hipStream_t st);
+
 // ---- decoder accumulation (wrappers.cpp:480, 513-514): acc = 0; acc += q_l*deps_l + min_l, l in order
 struct DequantParams {
     const uint8_t* q[8];

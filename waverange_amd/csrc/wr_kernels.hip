@@ -443,6 +443,55 @@ void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, 
     }
 }
 
+// local-cutoff variant: one thread per physical position (a bijection onto wavelet space)
+__global__ __launch_bounds__(WR_RED_THREADS) void k_quant_local(double* __restrict__ x, size_t n, double aopt,
+                                                                double bopt, double deps, double minval,
+                                                                uint8_t* __restrict__ q, LocalCutoff lc,
+                                                                double* __restrict__ partial)
+{
+    const double nan = __builtin_nan("");
+    double lo = nan, hi = nan;
+    for (size_t jp = (size_t)blockIdx.x * blockDim.x + threadIdx.x; jp < n; jp += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(jp % (size_t)lc.nx), py = (int)((jp / (size_t)lc.nx) % (size_t)lc.ny);
+        const int pz = (int)(jp / (size_t)lc.nx / (size_t)lc.ny);
+        // ind_p2w_3d (waveletcdf97_3d.c:473-553); the "touched" flag is sticky across levels there
+        int c1 = lc.nx, c2 = lc.ny, c3 = lc.nz, i1 = px, i2 = py, i3 = pz, lvl = 0, touched = 0;
+        for (int k = 0; k < lc.wlev; k++) {
+            const int m1 = c1 / 2 + (c1 % 2 > 0), m2 = c2 / 2 + (c2 % 2 > 0), m3 = c3 / 2 + (c3 % 2 > 0);
+            if (c1 > 1 && i3 < c3 && i2 < c2 && i1 < c1) { i1 = (i1 % 2) ? i1 / 2 + m1 : i1 / 2; touched = 1; }
+            if (c2 > 1 && i3 < c3 && i2 < c2 && i1 < c1) { i2 = (i2 % 2) ? i2 / 2 + m2 : i2 / 2; touched = 1; }
+            if (c3 > 1 && i3 < c3 && i2 < c2 && i1 < c1) { i3 = (i3 % 2) ? i3 / 2 + m3 : i3 / 2; touched = 1; }
+            c1 = m1; c2 = m2; c3 = m3;
+            if (touched) lvl += 1;
+        }
+        double mask = lc.tolabs;
+        if (lvl <= 1) {  // LOC_CUTOFF_LVL (defs.h:42); lcl_prec (wrappers.cpp:55-64)
+            const int kx = (int)((double)px / (double)lc.nx * (double)lc.mx);
+            const int ky = (int)((double)py / (double)lc.ny * (double)lc.my);
+            const int kz = (int)((double)pz / (double)lc.nz * (double)lc.mz);
+            mask = lc.tol_scale * lc.cutoff[kx + lc.mx * ky + lc.mx * lc.my * kz];
+        }
+        const size_t jw = (size_t)i1 + (size_t)lc.nx * (size_t)i2 + (size_t)lc.nx * (size_t)lc.ny * (size_t)i3;
+        double v = x[jw];
+        unsigned char qq;
+        if (lc.span < mask) { qq = 0; v = minval; }
+        else qq = (unsigned char)(int)(aopt * v + bopt);
+        q[jw] = qq;
+        v = v - ((double)qq * deps + minval);
+        x[jw] = v;
+        mm_acc(v, lo, hi);
+    }
+    block_minmax(lo, hi, partial);
+}
+
+void quantize_plane_local(double* x, size_t n, double aopt, double bopt, double deps, double minval, uint8_t* q,
+                          const LocalCutoff& lc, double* partial, double* result, hipStream_t st)
+{
+    const int g = red_grid(n, 1);
+    hipLaunchKernelGGL(k_quant_local, dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, aopt, bopt, deps, minval, q, lc, partial);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g, result);
+}
+
 // =====================================================================================
 // decoder: acc = 0; for l in order: acc = acc + (q_l*deps_l + min_l)   (wrappers.cpp:480,513-514)
 // =====================================================================================
