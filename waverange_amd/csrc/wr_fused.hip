@@ -101,8 +101,19 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const double* __restrict__ src, size_t s_sy, size_t s_sz,  // level input (x stride 1)
     double* __restrict__ dst, size_t d_sy, size_t d_sz,        // coefficient array (final positions)
     double* __restrict__ low, size_t l_sy, size_t l_sz,        // low-pass octant destination
-    int n1, int n2, int n3, int zps)
+    int n1, int n2, int n3, int zps
+#ifdef WR_STAMP
+    , unsigned long long* __restrict__ stamp_out  // diagnostic build: per-workgroup phase cycle sums
+#endif
+    )
 {
+#ifdef WR_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); ph[i] += tn_ - tprev; tprev = tn_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
     extern __shared__ double2 lds2[];
     double2* raw = lds2;                                          // [2][RROWS][RX]
     double* xl = reinterpret_cast<double*>(lds2 + 2 * NCHUNK);   // [RROWS][2*TXP]
@@ -143,33 +154,42 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
     const int iL = m1 - 1 - px0;  // local index of the last x-pair of the domain (right-edge tiles)
 
-    // x lifting of every staged row of plane p -> xl
+    // x lifting of every staged row of plane p -> xl.  Wave w owns rows w, w+NWAVE, ...
+    // First the mirrored x halo of those rows is patched (edge tiles only), THEN all rows are
+    // read: with no LDS store between the reads of consecutive rows the compiler can issue the
+    // next row's ds_read_b128s while the current row's lifting chain is still executing.
+    constexpr int XR = (RROWS + NWAVE - 1) / NWAVE;  // rows per wave (5)
+    constexpr int XFULL = RROWS / NWAVE;             // rounds in which every wave has a row (4)
     auto xlift = [&](int p) {
-        const double2* rp = raw + p * NCHUNK;
-#pragma unroll
-        for (int k = 0; k < (RROWS + NWAVE - 1) / NWAVE; k++) {
-            const int row = w + NWAVE * k;
-            if (row < RROWS) {
-                // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
-                // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3])
-                if (left_edge && lane < 2) {
-                    double2* e = const_cast<double2*>(rp) + row * RX;
-                    e[lane] = lane ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
+        double2* rp = raw + p * NCHUNK;
+        if (left_edge | right_edge) {
+            // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
+            // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3])
+            if (lane < 2 * XR) {
+                const int row = w + NWAVE * (lane >> 1);
+                if (row < RROWS) {
+                    double2* e = rp + row * RX;
+                    if (left_edge) e[lane & 1] = (lane & 1) ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
+                    if (right_edge) {
+                        double2* f = e + iL + 3 + (lane & 1);
+                        f[0] = (lane & 1) ? make_double2(f[-3].x, f[-4].y) : make_double2(f[-1].x, f[-2].y);
+                    }
                 }
-                if (right_edge && lane < 2) {
-                    double2* e = const_cast<double2*>(rp) + row * RX + iL + 3 + lane;
-                    e[0] = lane ? make_double2(e[-3].x, e[-4].y) : make_double2(e[-1].x, e[-2].y);
-                }
-                const double2* r = rp + row * RX + lane;
-                const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
-                const double s[5] = {v0.x, v1.x, v2.x, v3.x, v4.x};
-                const double d[4] = {v0.y, v1.y, v2.y, v3.y};
-                double lo, hi;
-                lift_fwd_center(s, d, lo, hi);
-                xl[row * (2 * TXP) + lane] = lo;
-                xl[row * (2 * TXP) + TXP + lane] = hi;
             }
         }
+        auto one_row = [&](int row) {
+            const double2* r = rp + row * RX + lane;
+            const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
+            const double s[5] = {v0.x, v1.x, v2.x, v3.x, v4.x};
+            const double d[4] = {v0.y, v1.y, v2.y, v3.y};
+            double lo, hi;
+            lift_fwd_center(s, d, lo, hi);
+            xl[row * (2 * TXP) + lane] = lo;
+            xl[row * (2 * TXP) + TXP + lane] = hi;
+        };
+#pragma unroll
+        for (int k = 0; k < XFULL; k++) one_row(w + NWAVE * k);
+        if (XR > XFULL && w + NWAVE * XFULL < RROWS) one_row(w + NWAVE * XFULL);
     };
     // y lifting of this thread's two y-pairs (2w, 2w+1) for its two x columns:
     // out[4*yp + {0,1,2,3}] = {LL, HL, LH, HH} of y-pair yp
@@ -203,17 +223,29 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
         for (int q = 0; q < 8; q++) a[q] = b[q] = 0.0;
         if (t < m3) {  // block-uniform
             const bool more = t + 1 <= te && t + 1 < m3;
+            STAMP(7);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks of planes 2t, 2t+1 have landed
+            STAMP(0);
             __syncthreads();                      // ... and everybody else's
+            STAMP(1);
             xlift(0);
+            STAMP(2);
             __syncthreads();
+            STAMP(6);
             if (more) fetch(t + 1, 0);  // raw[0] is free again: next even plane streams in behind the compute
+            STAMP(3);
             ylift(a);
+            STAMP(4);
             __syncthreads();
+            STAMP(6);
             xlift(1);
+            STAMP(2);
             __syncthreads();
+            STAMP(6);
             if (more) fetch(t + 1, 1);
+            STAMP(3);
             ylift(b);
+            STAMP(4);
         }
         // ---- z step: (a, b) is z-pair t  (waveletcdf97_3d.c:228-262)
 #pragma unroll
@@ -229,8 +261,10 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                 const double D2 = (j < m3 - 1) ? p1[q] + WR_GAMMA * (S1 + q1[q]) : p1[q] + (WR_GAMMA * 2) * q1[q];
                 const double S2 = (j > 0) ? q1[q] + WR_DELTA * (D2 + p2[q]) : q1[q] + (WR_DELTA * 2) * D2;
                 const int yp = q >> 2;  // which of the two y-pairs
+                // wave-uniform plane bases + per-lane 32-bit offsets (saddr form).  Trading values
+                // between lane pairs for 16-byte stores was measured 3 % SLOWER (per-lane 64-bit
+                // addresses, DPP + selects) -- profiles/r01/NOTES.md.
                 if (own_x && oy + yp < m2 && j >= z0 && j < z1) {
-                    // wave-uniform plane bases, per-lane 32-bit offsets
                     double* base = dst + ((q & 1) ? oct_x : 0) + ((q & 2) ? oct_y : 0) + (size_t)yp * d_sy;
                     if ((q & 3) == 0) (low + (size_t)j * l_sz + (size_t)yp * l_sy)[lpos] = S2 * WR_ZETA;
                     else (base + (size_t)j * d_sz)[pos0] = S2 * WR_ZETA;
@@ -240,7 +274,12 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             }
             p1[q] = D1; q1[q] = S1; sr1[q] = a[q]; dr1[q] = b[q];
         }
+        STAMP(5);
     }
+#ifdef WR_STAMP
+    if (stamp_out && lane == 0)
+        for (int i = 0; i < 8; i++) stamp_out[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVE + w) * 8 + i] = ph[i];
+#endif
 }
 
 
@@ -530,6 +569,16 @@ static int pick_zps(int tiles, int m3, int per_round)
     return best;
 }
 
+#ifdef WR_STAMP
+// diagnostic build only: phase stamps of the level-0 launch land here (8 x u64 per wave)
+unsigned long long* g_stamp_buf = nullptr;
+extern "C" unsigned long long* wr_stamp_buffer(size_t nwaves)
+{
+    if (!g_stamp_buf) { (void)hipMalloc(&g_stamp_buf, nwaves * 8 * sizeof(unsigned long long)); (void)hipMemset(g_stamp_buf, 0, nwaves * 64); }
+    return g_stamp_buf;
+}
+#endif
+
 void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
     static bool attr_set = false;
@@ -551,8 +600,13 @@ void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx,
         const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
         const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_BYTES));
         dim3 grid(tiles, (m3 + zps - 1) / zps);
+#ifdef WR_STAMP
+        hipLaunchKernelGGL(k_fwd_fused, grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
+                           lo_sz, n1, n2, n3, zps, l == 0 ? g_stamp_buf : nullptr);
+#else
         hipLaunchKernelGGL(k_fwd_fused, grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
                            lo_sz, n1, n2, n3, zps);
+#endif
         in = lo; in_sy = lo_sy; in_sz = lo_sz;
         lb += (size_t)m1 * m2 * m3;
     }
