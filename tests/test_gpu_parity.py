@@ -253,6 +253,12 @@ def test_large_roundtrip_properties(ctx, oracle):
     buf.upload(orig)
     enc, tm = ctx.encode(buf, (n, n, n), 1e-5)
     assert 1 <= enc["nlay"] <= 8 and sum(enc["len_enc_vec"]) == enc["ntot_enc"]
+    # config 2 (512^3, tol 1e-5) against the oracle: header scalars and every coded byte
+    want = oracle.encode(orig.reshape(n, n, n), 1e-5)
+    assert enc["len_enc_vec"] == want["len_enc_vec"] and enc["tolabs"] == want["tolabs"]
+    assert bits_equal(enc["deps_vec"], want["deps_vec"]) and bits_equal(enc["minval_vec"], want["minval_vec"])
+    assert np.array_equal(enc["data"], want["data"])
+    del want
     off = 0
     for ln in enc["len_enc_vec"]:
         assert enc["data"][off] == 0
@@ -281,3 +287,51 @@ def test_local_cutoff_branch(ctx, oracle, shape, m):
     ctx.decode(buf, f.shape, enc)
     assert bits_equal(buf.download(np.float64, f.size), oracle.decode(want, f.shape))
     buf.free()
+
+
+def test_full_size_1024_fused_vs_general_and_roundtrip(ctx, api):
+    """BASELINE full size (1024^3 fp64, 8 GiB).  No CPU oracle at this size, so:
+    (1) the fused single-pass kernels and the general 3-pass kernels -- two independent device
+        implementations, each pinned to the oracle at small sizes -- must agree bit for bit,
+        forward and inverse (compared on the device, max|a-b| == 0);
+    (2) encode -> decode at tol 1e-3 reconstructs within the tolerance band, the plane streams
+        carry the format anchors and their lengths add up."""
+    import os
+    n = 1024
+    shape = (n, n, n)
+    a = ctx.alloc(n ** 3 * 8)
+    b = ctx.alloc(n ** 3 * 8)
+    ctx.synth_field(a, n, n, n, 12345)
+    ctx.copy(b, a, n ** 3 * 8)
+    ctx.transform(a, shape, 4)                 # fused
+    os.environ["WR_NO_FUSED"] = "1"
+    try:
+        ctx.transform(b, shape, 4)             # general
+        diff, amax = ctx.linf(a, b, n ** 3)
+        assert diff == 0.0 and amax > 0
+        ctx.transform(b, shape, -4)            # general inverse
+    finally:
+        del os.environ["WR_NO_FUSED"]
+    ctx.transform(a, shape, -4)                # fused inverse
+    diff, _ = ctx.linf(a, b, n ** 3)
+    assert diff == 0.0
+    ctx.synth_field(b, n, n, n, 12345)
+    diff, amax = ctx.linf(b, a, n ** 3)        # forward + inverse is the identity up to round-off
+    assert diff < 1e-12 * amax
+    enc, tm = ctx.encode(a, shape, 1e-3)
+    assert 1 <= enc["nlay"] <= 8 and sum(enc["len_enc_vec"]) == enc["ntot_enc"]
+    off = 0
+    for ln in enc["len_enc_vec"]:
+        s = enc["data"]
+        assert s[off] == 0
+        assert (int(s[off + ln - 3]) << 16 | int(s[off + ln - 2]) << 8 | int(s[off + ln - 1])) == ln % (1 << 24)
+        off += ln
+    ctx.decode(a, shape, enc)
+    diff, amax = ctx.linf(b, a, n ** 3)
+    # The reference's own error control is approximate (SURVEY.md Q5: 1.013e-3 at 256^3 for tol
+    # 1e-3; WAV_ACC_COEF = 1.75 is an empirical allowance for the 4-level synthesis gain).  At
+    # 1024^3 the same arithmetic gives 1.09e-3; 512^3 is compared with the oracle bit for bit in
+    # test_large_roundtrip_properties, so this only guards the order of magnitude.
+    assert diff / amax < 1.25e-3
+    a.free()
+    b.free()

@@ -151,7 +151,11 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             }
         }
     };
+#ifdef WR_NOPATCH
+    const bool left_edge = false, right_edge = false;  // timing experiment only: wrong results at the x edges
+#else
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
+#endif
     const int iL = m1 - 1 - px0;  // local index of the last x-pair of the domain (right-edge tiles)
 
     // x lifting of every staged row of plane p -> xl.  Wave w owns rows w, w+NWAVE, ...
@@ -409,7 +413,11 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         }
     };
 
+#ifdef WR_NOPATCH
+    const bool left_edge = false, right_edge = false;
+#else
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
+#endif
     const int iL = m1 - 1 - px0;
     double* ybw = yb + w * (2 * 2 * HX);  // this wave's two rows of [xlow 68 | xhigh 68]
     const int J = 2 * w;                   // first of this wave's two local y-pairs
