@@ -18,6 +18,8 @@ BIN = os.path.join(HERE, "bin")
 
 SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_rangecoder.cpp", "wr_compat.cpp"]
 CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"]}
+# FluSI HDF5 front-end (libhdf5 is looked up at run time: HDF5_ROOT, the default path, /opt/conda)
+FLUSI = {"wrenc_flusi": ["cli/flusi_enc.cpp", "cli/flusi_h5.cpp"], "wrdec_flusi": ["cli/flusi_dec.cpp", "cli/flusi_h5.cpp"]}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
           "-Wno-unused-result", "-march=x86-64-v3"]
 
@@ -71,6 +73,19 @@ def build(force=False, verbose=True):
             cmd = [hipcc, "-O2", "-std=c++17", "-ffp-contract=off", "-x", "c++"] + paths + [
                 "-x", "none", "-o", exe, "-L" + HERE, "-lwaverange_amd", "-Wl,-rpath," + HERE,
                 "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    # FluSI HDF5 front-end: libhdf5 is bound with dlopen at run time, so it always builds
+    for name, srcs in FLUSI.items():
+        paths = [os.path.join(CSRC, s) for s in srcs]
+        if not all(os.path.exists(p) for p in paths):
+            continue
+        exe = os.path.join(BIN, name)
+        if force or _stale(exe, deps + [LIB]):
+            os.makedirs(BIN, exist_ok=True)
+            cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off"] + paths + [
+                "-o", exe, "-L" + HERE, "-lwaverange_amd", "-ldl", "-lpthread", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

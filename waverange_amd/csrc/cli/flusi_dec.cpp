@@ -1,0 +1,115 @@
+// wrdec (FluSI) -- HDF5 front-end of the decoder, reference src/flusi/main_dec.cpp.
+//   wrdec compressed_000.h5 decompressed_000.h5 TYPE PRECISION   PRECISION 1: single, 2: double
+#include <cmath>
+
+#include "flusi_common.h"
+#include "flusi_h5.h"
+
+using std::cout;
+using std::endl;
+using std::string;
+
+namespace {
+struct Item {
+    string name;
+    int nx = 0, ny = 0, nz = 0;
+    bool backup = false;
+    double bckp[8] = {0};
+    double time = 0, nu = 0, epsi = 0, domain[3] = {0, 0, 0};
+    int nxyz[3] = {0, 0, 0};
+    std::vector<unsigned char> data;
+    std::vector<double> rec;
+    wr_enc_info info;
+    std::future<int> done;
+};
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    static const char* const keys[4] = {"&in_name", "&out_name", "&file_type", "&precision"};
+    static const char* const prompts[4] = {"Enter compressed data file name []: ", "Enter reconstructed file name []: ",
+                                           "Enter file type (0: regular output; 1: backup) [0]: ",
+                                           "Enter output data type (1: float; 2: double) [2]: "};
+    string p[4];
+    if (!flusi::get_params(argc, argv, false, keys, prompts,
+                           "usage: ./wrdec compressed_000.h5 decompressed_000.h5 TYPE PRECISION\n"
+                           "where TYPE=(0: regular output; 1: backup) and PRECISION=(1:single; 2:double)\n"
+                           "interactive mode if not enough arguments are passed.\n", p))
+        return -1;
+    int file_type = 0, outtype = 1;  // main_dec.cpp:66 defaults
+    std::stringstream(p[2]) >> file_type;
+    std::stringstream(p[3]) >> outtype;
+    const string in_name = p[0], out_name = p[1];
+    cout << endl << "=== Decoding parameters ===" << endl;
+    cout << "Input file name: " << in_name << endl << "Output file name: " << out_name << endl;
+    cout << "File type (0: regular output; 1: backup): " << file_type << endl;
+    cout << "Output data type (1: float; 2: double): " << outtype << endl;
+    if (file_type != 0 && file_type != 1) { cout << "Error: unknown file type" << endl; return 0; }
+
+    flusi::create_file(out_name);
+    std::vector<string> names;
+    if (file_type == 0) {
+        std::vector<string> all = flusi::dataset_names(in_name);
+        if (all.empty()) { cout << "no dataset in " << in_name << endl; return 1; }
+        names.push_back(all.back());
+    } else {
+        for (const char* n : flusi::kBackupNames)
+            if (flusi::has_dataset(in_name, n)) names.push_back(n);
+    }
+    flusi::Pipeline pipe;
+    if (!pipe.open()) return 1;
+    std::vector<Item> items(names.size());
+    auto finish = [&](Item& it) {
+        if (it.done.get() != WR_OK) { std::cerr << "wrdec: " << it.name << ": " << wr_last_error() << endl; exit(1); }
+        const size_t n = it.rec.size();
+        cout << "  decode: fld_1d_rec[0]=" << it.rec[0] << " fld_1d_rec[last]=" << it.rec[n - 1] << endl;
+        double lo = it.rec[0], hi = it.rec[0];
+        for (size_t j = 0; j < n; j++) { lo = fmin(lo, it.rec[j]); hi = fmax(hi, it.rec[j]); }
+        cout << "        min=" << lo << " max=" << hi << endl;
+        flusi::write_field(out_name, it.name, it.rec.data(), it.nx, it.ny, it.nz, outtype == 1);
+        if (it.backup) flusi::write_attr_double(out_name, it.name, "bckp", it.bckp, 8);
+        else {
+            flusi::write_attr_double(out_name, it.name, "time", &it.time, 1);
+            flusi::write_attr_double(out_name, it.name, "viscosity", &it.nu, 1);
+            flusi::write_attr_double(out_name, it.name, "epsi", &it.epsi, 1);
+            flusi::write_attr_double(out_name, it.name, "domain_size", it.domain, 3);
+            flusi::write_attr_int(out_name, it.name, "nxyz", it.nxyz, 3);
+        }
+        std::vector<double>().swap(it.rec);
+    };
+    for (size_t k = 0; k < items.size(); k++) {
+        Item& it = items[k];
+        it.name = names[k];
+        it.backup = file_type == 1;
+        if (it.backup) {
+            if (!flusi::read_attr_double(in_name, it.name, "bckp", it.bckp, 8)) { cout << it.name << ": no bckp attribute" << endl; return 1; }
+            it.nx = int(it.bckp[5]); it.ny = int(it.bckp[6]); it.nz = int(it.bckp[7]);
+        } else {
+            bool ok = flusi::read_attr_double(in_name, it.name, "time", &it.time, 1);
+            ok &= flusi::read_attr_double(in_name, it.name, "viscosity", &it.nu, 1);
+            ok &= flusi::read_attr_double(in_name, it.name, "epsi", &it.epsi, 1);
+            ok &= flusi::read_attr_double(in_name, it.name, "domain_size", it.domain, 3);
+            ok &= flusi::read_attr_int(in_name, it.name, "nxyz", it.nxyz, 3);
+            if (!ok) { cout << it.name << ": regular-output attributes missing" << endl; return 1; }
+            it.nx = it.nxyz[0]; it.ny = it.nxyz[1]; it.nz = it.nxyz[2];
+        }
+        cout << " dset=" << it.name << " nx=" << it.nx << " ny=" << it.ny << " nz=" << it.nz << endl;
+        flusi::read_coded(in_name, it.name, it.data, it.info);
+        const size_t n = (size_t)it.nx * it.ny * it.nz;
+        const int slot = (int)(k & 1);
+        if (k >= 2) finish(items[k - 2]);
+        double* d_fld = pipe.field(slot, n);
+        if (!d_fld) { std::cerr << "wrdec: " << wr_last_error() << endl; return 1; }
+        it.rec.resize(n);
+        wr_ctx* c = pipe.ctx[slot];
+        Item* ip = &it;
+        it.done = std::async(std::launch::async, [c, d_fld, ip, n]() {
+            if (int rc = wr_decode_device(c, d_fld, ip->nx, ip->ny, ip->nz, &ip->info, ip->data.data(), nullptr)) return rc;
+            std::vector<unsigned char>().swap(ip->data);
+            return wr_dev_download(c, ip->rec.data(), d_fld, n * sizeof(double));
+        });
+    }
+    for (size_t k = items.size() >= 2 ? items.size() - 2 : 0; k < items.size(); k++) finish(items[k]);
+    cout << "=== End of decompression ===\n";
+    return 0;
+}

@@ -1,0 +1,124 @@
+// wrenc (FluSI) -- HDF5 front-end of the encoder, reference src/flusi/main_enc.cpp.
+//   wrenc original_000.h5 compressed_000.h5 TYPE TOLERANCE     TYPE 0: regular output, 1: backup
+// Regular files hold one dataset with attributes time / viscosity / epsi / domain_size / nxyz;
+// backup files hold up to 50 named datasets with a `bckp` attribute (main_enc.cpp:319-330).
+// Datasets are pipelined over two GPU contexts (BASELINE config 5: overlap across ux, uy, uz).
+#include <cmath>
+
+#include "flusi_common.h"
+#include "flusi_h5.h"
+
+using std::cout;
+using std::endl;
+using std::string;
+
+namespace {
+
+struct Item {
+    string name;
+    int nx = 0, ny = 0, nz = 0;
+    bool backup = false;
+    double bckp[8] = {0};
+    double time = 0, nu = 0, epsi = 0, domain[3] = {0, 0, 0};
+    int nxyz[3] = {0, 0, 0};
+    std::vector<double> fld;
+    std::vector<unsigned char> data;
+    wr_enc_info info;
+    std::future<int> done;
+};
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    static const char* const keys[4] = {"&in_name", "&out_name", "&file_type", "&tolerance"};
+    static const char* const prompts[4] = {"Enter input file name []: ", "Enter output file name []: ",
+                                           "Enter file type (0: regular output; 1: backup) [0]: ",
+                                           "Enter base cutoff relative tolerance [1e-16]: "};
+    string p[4];
+    if (!flusi::get_params(argc, argv, true, keys, prompts,
+                           "usage: ./wrenc original_000.h5 compressed_000.h5 TYPE TOLERANCE\n"
+                           "where TYPE=(0: regular output; 1: backup) and TOLERANCE=(e.g. 1.0e-5)\n"
+                           "interactive mode if not enough arguments are passed.\n", p))
+        return -1;
+    int file_type = 0;
+    double tol = 1e-16;
+    std::stringstream(p[2]) >> file_type;
+    std::stringstream(p[3]) >> tol;
+    const string in_name = p[0], out_name = p[1];
+    cout << endl << "=== Compression parameters ===" << endl;
+    cout << "Input file name: " << in_name << endl << "Output file name: " << out_name << endl;
+    cout << "File type (0: regular output; 1: backup): " << file_type << endl;
+    cout << "Base cutoff relative tolerance: " << tol << endl;
+    if (file_type != 0 && file_type != 1) { cout << "Error: unknown file type" << endl; return 0; }
+
+    flusi::create_file(out_name);
+    std::vector<string> names;
+    if (file_type == 0) {
+        std::vector<string> all = flusi::dataset_names(in_name);
+        if (all.empty()) { cout << "no dataset in " << in_name << endl; return 1; }
+        names.push_back(all.back());  // the reference keeps the last dataset its H5Ovisit callback sees
+    } else {
+        for (const char* n : flusi::kBackupNames)
+            if (flusi::has_dataset(in_name, n)) names.push_back(n);
+    }
+
+    flusi::Pipeline pipe;
+    if (!pipe.open()) return 1;
+    std::vector<Item> items(names.size());
+    auto finish = [&](Item& it) {  // in dataset order: wait for the codec, then write (main thread owns HDF5)
+        if (it.done.get() != WR_OK) { std::cerr << "wrenc: " << it.name << ": encode failed" << endl; exit(1); }
+        cout << "        tolabs=" << it.info.tolabs << endl;
+        flusi::write_coded(out_name, it.name, it.data.data(), it.info);
+        if (it.backup) flusi::write_attr_double(out_name, it.name, "bckp", it.bckp, 8);
+        else {
+            flusi::write_attr_double(out_name, it.name, "time", &it.time, 1);
+            flusi::write_attr_double(out_name, it.name, "viscosity", &it.nu, 1);
+            flusi::write_attr_double(out_name, it.name, "epsi", &it.epsi, 1);
+            flusi::write_attr_double(out_name, it.name, "domain_size", it.domain, 3);
+            flusi::write_attr_int(out_name, it.name, "nxyz", it.nxyz, 3);
+        }
+        std::vector<unsigned char>().swap(it.data);
+    };
+    for (size_t k = 0; k < items.size(); k++) {
+        Item& it = items[k];
+        it.name = names[k];
+        it.backup = file_type == 1;
+        if (it.backup) {
+            if (!flusi::read_attr_double(in_name, it.name, "bckp", it.bckp, 8)) { cout << it.name << ": no bckp attribute" << endl; return 1; }
+            it.nx = int(it.bckp[5]); it.ny = int(it.bckp[6]); it.nz = int(it.bckp[7]);  // main_enc.cpp:469-474
+        } else {
+            bool ok = flusi::read_attr_double(in_name, it.name, "time", &it.time, 1);
+            ok &= flusi::read_attr_double(in_name, it.name, "viscosity", &it.nu, 1);
+            ok &= flusi::read_attr_double(in_name, it.name, "epsi", &it.epsi, 1);
+            ok &= flusi::read_attr_double(in_name, it.name, "domain_size", it.domain, 3);
+            ok &= flusi::read_attr_int(in_name, it.name, "nxyz", it.nxyz, 3);
+            if (!ok) { cout << it.name << ": regular-output attributes missing" << endl; return 1; }
+            it.nx = it.nxyz[0]; it.ny = it.nxyz[1]; it.nz = it.nxyz[2];
+        }
+        cout << " dset=" << it.name << " nx=" << it.nx << " ny=" << it.ny << " nz=" << it.nz << endl;
+        const size_t n = (size_t)it.nx * it.ny * it.nz;
+        flusi::read_field(in_name, it.name, it.fld, n);
+        cout << "  read: fld_1d[0]=" << it.fld[0] << " fld_1d[last]=" << it.fld[n - 1] << endl;
+        double lo = it.fld[0], hi = it.fld[0];
+        for (size_t j = 0; j < n; j++) { lo = fmin(lo, it.fld[j]); hi = fmax(hi, it.fld[j]); }
+        cout << "        min=" << lo << " max=" << hi << endl;
+        const int slot = (int)(k & 1);
+        if (k >= 2) finish(items[k - 2]);  // frees this slot's context
+        unsigned char nl; unsigned long cap;
+        setup_wr(it.nx, it.ny, it.nz, &nl, &cap);
+        it.data.resize(cap);
+        double* d_fld = pipe.field(slot, n);
+        if (!d_fld) { std::cerr << "wrenc: " << wr_last_error() << endl; return 1; }
+        wr_ctx* c = pipe.ctx[slot];
+        Item* ip = &it;
+        it.done = std::async(std::launch::async, [c, d_fld, ip, n, tol]() {
+            if (int rc = wr_dev_upload(c, d_fld, ip->fld.data(), n * sizeof(double))) return rc;
+            std::vector<double>().swap(ip->fld);
+            return wr_encode_device(c, d_fld, ip->nx, ip->ny, ip->nz, 1, tol, &ip->info, ip->data.data(), ip->data.size(), nullptr);
+        });
+    }
+    for (size_t k = items.size() >= 2 ? items.size() - 2 : 0; k < items.size(); k++) finish(items[k]);
+    cout << "=== End of compression ===\n";
+    return 0;
+}
