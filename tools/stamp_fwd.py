@@ -16,13 +16,16 @@ ptr = L.wr_stamp_buffer(nw)
 buf = ctx.alloc(n ** 3 * 8)
 ctx.synth_field(buf, n, n, n, 12345)
 ctx.sync()
+inv = len(sys.argv) > 2 and sys.argv[2] == "inv"
 for r in range(3):
-    print("fwd ms", ctx.bench_transform(buf, (n, n, n), 4, 1))
+    print("ms", ctx.bench_transform(buf, (n, n, n), -4 if inv else 4, 1))
 out = np.zeros(nw * 8, dtype=np.uint64)
 L.wr_dev_download(ctx.h, out.ctypes.data, ptr, out.nbytes)
 a = out.reshape(-1, 8).astype(np.float64)
 a = a[a.sum(axis=1) > 0] / 3.0   # three launches accumulated? no: overwritten each launch
 names = ["wait_dma", "barrier_top", "xlift", "fetch_issue", "ylift", "zstep+stores", "barriers_mid", "loop_top"]
+if inv:
+    names = ["wait_dma", "barrier_top", "zstep(+zb write)", "fetch_issue", "y+x stages", "odd plane -> zb", "barriers_mid", "loop_top"]
 tot = a.sum(axis=1).mean()
 print("waves with stamps:", len(a), "mean cycles/wave:", tot * 3)
 for i, nm in enumerate(names):

@@ -34,6 +34,10 @@ namespace wrk {
 #define WR_ZETA (0x1.264c795071464p+0)
 #define WR_IZETA (0x1.bd5edf975ce17p-1)
 
+#ifdef WR_STAMP
+unsigned long long* g_stamp_buf = nullptr;
+#endif
+
 namespace {
 
 constexpr int TXP = 64;             // x-pairs per tile
@@ -48,6 +52,24 @@ constexpr int NTHR = 32 * TYP;      // one thread = one x-pair x two y-pairs
 constexpr int NWAVE = NTHR / 64;
 constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (3)
 constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * 2 * TXP * 8;
+
+// blockIdx.x -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (b % 8
+// says which share an L2).  The plain row-major order gives every XCD one COLUMN of tiles when there
+// are 8 tile columns: y halos hit in L2, x halos never do.  Here an XCD gets a block 2 tiles wide
+// and tiles_y/2 tall instead, so half of the x halos are shared too (speed only: inverse -1.5 %).
+__device__ inline void tile_of_block(int b, int tiles_x, int tiles_y, int& tx, int& ty)
+{
+#ifndef WR_NO_XCD_BLOCK
+    if (tiles_x == 8 && (tiles_y & 1) == 0) {
+        const int xcd = b & 7, j = b >> 3;  // j-th workgroup of this XCD
+        tx = 2 * (xcd & 3) + (j & 1);
+        ty = (xcd >> 2) * (tiles_y >> 1) + (j >> 1);
+        return;
+    }
+#endif
+    tx = b % tiles_x;
+    ty = b / tiles_x;
+}
 
 __device__ inline int mirror(int v, int n)
 {
@@ -120,7 +142,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + TXP - 1) / TXP;
-    const int px0 = (blockIdx.x % tiles_x) * TXP, py0 = (blockIdx.x / tiles_x) * TYP;
+    int tile_x, tile_y;
+    tile_of_block(blockIdx.x, tiles_x, (m2 + TYP - 1) / TYP, tile_x, tile_y);
+    const int px0 = tile_x * TXP, py0 = tile_y * TYP;
     const int z0 = blockIdx.y * zps;
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
@@ -169,8 +193,13 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
         if (left_edge | right_edge) {
             // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
             // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3])
+#ifdef WR_XLIFT1
             if (lane < 2 * XR) {
                 const int row = w + NWAVE * (lane >> 1);
+#else
+            if (lane < 4 * ((RROWS + 2 * NWAVE - 1) / (2 * NWAVE))) {
+                const int row = 2 * (w + NWAVE * (lane >> 2)) + ((lane >> 1) & 1);
+#endif
                 if (row < RROWS) {
                     double2* e = rp + row * RX;
                     if (left_edge) e[lane & 1] = (lane & 1) ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
@@ -181,6 +210,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                 }
             }
         }
+#ifdef WR_XLIFT1
         auto one_row = [&](int row) {
             const double2* r = rp + row * RX + lane;
             const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
@@ -194,6 +224,27 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
 #pragma unroll
         for (int k = 0; k < XFULL; k++) one_row(w + NWAVE * k);
         if (XR > XFULL && w + NWAVE * XFULL < RROWS) one_row(w + NWAVE * XFULL);
+#else
+        // two adjacent x-pairs per lane (14 lifting steps instead of 20): a wave covers two rows
+        // per round, lanes 0-31 the first, lanes 32-63 the second
+        const int half = lane >> 5, jp = (lane & 31) * 2;  // first of this lane's two x-pairs
+        auto two_rows = [&](int row) {
+            const double2* r = rp + row * RX + jp;
+            const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5];
+            const double s[6] = {v0.x, v1.x, v2.x, v3.x, v4.x, v5.x};
+            const double d[5] = {v0.y, v1.y, v2.y, v3.y, v4.y};
+            double lo0, hi0, lo1, hi1;
+            lift_fwd_two(s, d, lo0, hi0, lo1, hi1);
+            *reinterpret_cast<double2*>(xl + row * (2 * TXP) + jp) = make_double2(lo0, lo1);
+            *reinterpret_cast<double2*>(xl + row * (2 * TXP) + TXP + jp) = make_double2(hi0, hi1);
+        };
+        constexpr int XR2 = (RROWS + 2 * NWAVE - 1) / (2 * NWAVE);  // rounds of 2*NWAVE rows (3)
+#pragma unroll
+        for (int k = 0; k < XR2; k++) {
+            const int row = 2 * (w + NWAVE * k) + half;
+            if (row < RROWS) two_rows(row);
+        }
+#endif
     };
     // y lifting of this thread's two y-pairs (2w, 2w+1) for its two x columns:
     // out[4*yp + {0,1,2,3}] = {LL, HL, LH, HH} of y-pair yp
@@ -366,8 +417,15 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     const double* __restrict__ src, size_t s_sy, size_t s_sz,  // coefficient array (detail octants)
     const double* __restrict__ low, size_t l_sy, size_t l_sz,  // low-pass octant (previous level's output)
     double* __restrict__ out, size_t o_sy, size_t o_sz,        // reconstructed box of this level
-    int n1, int n2, int n3, int zps)
+    int n1, int n2, int n3, int zps
+#ifdef WR_STAMP
+    , unsigned long long* __restrict__ stamp_out
+#endif
+    )
 {
+#ifdef WR_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ double2 lds2[];
     double2* in = lds2;                   // [2][NCI]   staged low-z / high-z coefficient planes
     double2* zb = lds2 + 2 * NCI;         // [NCI]      one z-reconstructed plane
@@ -375,7 +433,9 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + TXP - 1) / TXP;
-    const int px0 = (blockIdx.x % tiles_x) * TXP, py0 = (blockIdx.x / tiles_x) * ITYP;
+    int tile_x, tile_y;
+    tile_of_block(blockIdx.x, tiles_x, (m2 + ITYP - 1) / ITYP, tile_x, tile_y);
+    const int px0 = tile_x * TXP, py0 = tile_y * ITYP;
     const int z0 = blockIdx.y * zps;
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
@@ -434,6 +494,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
             if (lane & 1) { r[iL + 3] = r[iL + 2]; r[iL + 4] = r[iL + 1]; }            // s[m] = s[m-1], s[m+1] = s[m-2]
             else { r[HX + iL + 3] = r[HX + iL + 1]; r[HX + iL + 4] = r[HX + iL]; }     // d[m] = d[m-2], d[m+1] = d[m-3]
         }
+#ifdef WR_XINV1
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const double* row = ybw + r * (2 * HX);
@@ -447,6 +508,25 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                 *reinterpret_cast<double2*>(out + (size_t)zplane * o_sz + (size_t)y * o_sy + 2 * (px0 + lane)) =
                     make_double2(ev, od);
         }
+#else
+        {   // two adjacent x-pairs per lane (14 lifting steps instead of 20): lanes 0-31 take the
+            // first of the two rows, lanes 32-63 the second
+            const int r = lane >> 5, i = (lane & 31) * 2;
+            const double* row = ybw + r * (2 * HX);
+            // local column of pair k is k + 2:  s[i-1..i+3] -> i+1..i+5,  d[i-2..i+3] -> i..i+5
+            const double sr[5] = {row[i + 1], row[i + 2], row[i + 3], row[i + 4], row[i + 5]};
+            const double dr[6] = {row[HX + i], row[HX + i + 1], row[HX + i + 2], row[HX + i + 3], row[HX + i + 4],
+                                  row[HX + i + 5]};
+            double o[4];
+            lift_inv_two(sr, dr, o);
+            const int y = yrow0 + r;
+            double* dstp = out + (size_t)zplane * o_sz + (size_t)y * o_sy + 2 * (px0 + i);
+            if (y < n2) {
+                if (px0 + i < m1) *reinterpret_cast<double2*>(dstp) = make_double2(o[0], o[1]);
+                if (px0 + i + 1 < m1) *reinterpret_cast<double2*>(dstp + 2) = make_double2(o[2], o[3]);
+            }
+        }
+#endif
     };
     // y + x stages of the z-plane held in zb
     auto yxstage = [&](int zplane) {
@@ -492,8 +572,11 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         const int j = t - 2;
         const bool emit = j >= z0 && j < z1;  // block-uniform
         double2 odd[KCI];
+        STAMP(7);
         if (t < m3) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed
+        STAMP(0);
         __syncthreads();  // everybody's chunks have landed; the previous step's readers of zb are done
+        STAMP(1);
         // ---- z step on every staged point  (waveletcdf97_3d.c:312-337 along z)
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
@@ -528,18 +611,30 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                 odd[k] = make_double2(od[0], od[1]);
             }
         }
+        STAMP(2);
         __syncthreads();  // zb complete; `in` fully consumed
+        STAMP(6);
         if (t + 1 <= te && t + 1 < m3) fetch(t + 1);  // streams in behind the y/x stages
+        STAMP(3);
         if (emit) {
             yxstage(2 * j);
+            STAMP(4);
             __syncthreads();
+            STAMP(6);
 #pragma unroll
             for (int k = 0; k < KCI; k++)
                 if (tid + INTHR * k < NCI) zb[tid + INTHR * k] = odd[k];
+            STAMP(5);
             __syncthreads();
+            STAMP(6);
             yxstage(2 * j + 1);
+            STAMP(4);
         }
     }
+#ifdef WR_STAMP
+    if (stamp_out && lane == 0)
+        for (int i = 0; i < 8; i++) stamp_out[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * INWAVE + w) * 8 + i] = ph[i];
+#endif
 }
 
 bool fused_ok(int nx, int ny, int nz, int lvl)
@@ -579,7 +674,6 @@ static int pick_zps(int tiles, int m3, int per_round)
 
 #ifdef WR_STAMP
 // diagnostic build only: phase stamps of the level-0 launch land here (8 x u64 per wave)
-unsigned long long* g_stamp_buf = nullptr;
 extern "C" unsigned long long* wr_stamp_buffer(size_t nwaves)
 {
     if (!g_stamp_buf) { (void)hipMalloc(&g_stamp_buf, nwaves * 8 * sizeof(unsigned long long)); (void)hipMemset(g_stamp_buf, 0, nwaves * 64); }
@@ -646,8 +740,13 @@ void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx,
         const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + ITYP - 1) / ITYP);
         const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_INV));
         dim3 grid(tiles, (m3 + zps - 1) / zps);
+#ifdef WR_STAMP
+        hipLaunchKernelGGL(k_inv_fused, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
+                           n2, n3, zps, l == 0 ? g_stamp_buf : nullptr);
+#else
         hipLaunchKernelGGL(k_inv_fused, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
                            n2, n3, zps);
+#endif
     }
 }
 
