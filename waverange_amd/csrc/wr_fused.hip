@@ -71,6 +71,13 @@ __device__ inline void tile_of_block(int b, int tiles_x, int tiles_y, int& tx, i
     ty = b / tiles_x;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence, and
+// with global_load_lds in flight the compiler turns that into `s_waitcnt vmcnt(0)` in front of
+// the s_barrier: every mid-step barrier would drain the DMA that was issued to run BEHIND it.
+// Here the wave only waits for its own LDS reads/writes; the DMA is waited for explicitly at
+// the top of the next step (vmcnt(0) + barrier) by every wave that issued it.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline int mirror(int v, int n)
 {
     if (v < 0) v = -v;
@@ -285,17 +292,17 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             STAMP(1);
             xlift(0);
             STAMP(2);
-            __syncthreads();
+            lds_barrier();
             STAMP(6);
             if (more) fetch(t + 1, 0);  // raw[0] is free again: next even plane streams in behind the compute
             STAMP(3);
             ylift(a);
             STAMP(4);
-            __syncthreads();
+            lds_barrier();
             STAMP(6);
             xlift(1);
             STAMP(2);
-            __syncthreads();
+            lds_barrier();
             STAMP(6);
             if (more) fetch(t + 1, 1);
             STAMP(3);
@@ -456,13 +463,15 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         offL[k] = (q == 0) ? (int)(gyp * l_sy) + gxp : so;
         if (q == 0) lll_mask |= 1u << k;
     }
-    auto fetch = [&](int t) {
+    // chunk slots [k0, k1) of z-pair t; issued in three bursts spread over the step, because
+    // 96 global_load_lds per CU in one burst stall in the issue queue (profiles/r01/NOTES.md)
+    auto fetch = [&](int t, int k0, int k1) {
         const double* pl = src + (size_t)t * s_sz;         // low-z plane, detail quadrants
         const double* pll = low + (size_t)t * l_sz;        // low-z plane, LL quadrant
         const double* ph = src + (size_t)(m3 + t) * s_sz;  // high-z plane
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
-            if (tid + INTHR * k < NCI) {
+            if (k >= k0 && k < k1 && tid + INTHR * k < NCI) {
                 double2* l0 = in + INTHR * k + (w << 6);
                 const double* gl = ((lll_mask >> k) & 1) ? pll + offL[k] : pl + offL[k];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 #pragma unroll
         for (int e = 0; e < 2; e++) dprev[k][e] = s1prev[k][e] = d1prev[k][e] = s2prev[k][e] = 0.0;
 
-    if (tb < m3) fetch(tb);
+    if (tb < m3) fetch(tb, 0, KCI);
     for (int t = tb; t <= te; t++) {
         const int j = t - 2;
         const bool emit = j >= z0 && j < z1;  // block-uniform
@@ -612,21 +621,27 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
             }
         }
         STAMP(2);
-        __syncthreads();  // zb complete; `in` fully consumed
+        lds_barrier();  // zb complete; `in` fully consumed
         STAMP(6);
-        if (t + 1 <= te && t + 1 < m3) fetch(t + 1);  // streams in behind the y/x stages
+        const bool more = t + 1 <= te && t + 1 < m3;
+        constexpr int K1 = (KCI + 2) / 3, K2 = (2 * KCI + 2) / 3;
+        if (more) fetch(t + 1, 0, emit ? K1 : KCI);  // streams in behind the y/x stages
         STAMP(3);
         if (emit) {
             yxstage(2 * j);
             STAMP(4);
-            __syncthreads();
+            lds_barrier();
             STAMP(6);
+            if (more) fetch(t + 1, K1, K2);
+            STAMP(3);
 #pragma unroll
             for (int k = 0; k < KCI; k++)
                 if (tid + INTHR * k < NCI) zb[tid + INTHR * k] = odd[k];
             STAMP(5);
-            __syncthreads();
+            lds_barrier();
             STAMP(6);
+            if (more) fetch(t + 1, K2, KCI);
+            STAMP(3);
             yxstage(2 * j + 1);
             STAMP(4);
         }
