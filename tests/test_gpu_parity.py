@@ -335,3 +335,45 @@ def test_full_size_1024_fused_vs_general_and_roundtrip(ctx, api):
     assert diff / amax < 1.25e-3
     a.free()
     b.free()
+
+
+def test_api_error_paths(ctx, api):
+    """Part-2 functions return error codes (never crash, never fall back): too small an output buffer,
+    a corrupted / truncated stream, bad arguments."""
+    import ctypes as C
+    f = synth.field(32, 32, 32, seed=1)
+    buf = ctx.to_device(f)
+    enc, _ = ctx.encode(buf, f.shape, 1e-6)
+    enc["data"] = enc["data"].copy()
+    # output capacity too small -> WR_ERR_OVERFLOW (the reference throws here, wrappers.cpp:422-426)
+    buf.upload(f)
+    small = np.empty(enc["ntot_enc"] // 2, dtype=np.uint8)
+    with pytest.raises(api.WaveRangeError, match="encoded array is too large"):
+        ctx.encode(buf, f.shape, 1e-6, out=small)
+    # truncated stream: plane does not decode to nx*ny*nz symbols -> WR_ERR_STREAM
+    bad = dict(enc)
+    bad["data"] = enc["data"][: enc["ntot_enc"] // 2].copy()
+    with pytest.raises(api.WaveRangeError):
+        ctx.decode(buf, f.shape, bad)
+    # corrupted bytes in the middle of a plane: must not crash; either an error or a wrong field
+    bad = dict(enc)
+    d = enc["data"].copy()
+    d[len(d) // 3: len(d) // 3 + 64] ^= 0x5A
+    bad["data"] = d
+    try:
+        ctx.decode(buf, f.shape, bad)
+    except api.WaveRangeError:
+        pass
+    # nlay out of range, misaligned device pointer
+    bad = dict(enc)
+    bad["nlay"] = 9
+    with pytest.raises(Exception):
+        ctx.decode(buf, f.shape, bad)
+    info, tm = api.EncInfo(), api.Timings()
+    rc = api.lib().wr_encode_device(ctx.h, buf.ptr + 8, 32, 32, 32, 1, 1e-6, C.byref(info), small.ctypes.data, small.size, C.byref(tm))
+    assert rc != 0 and b"aligned" in api.lib().wr_last_error()
+    # after all these failures the context still works
+    buf.upload(f)
+    again, _ = ctx.encode(buf, f.shape, 1e-6)
+    assert np.array_equal(again["data"], enc["data"])
+    buf.free()
