@@ -87,6 +87,7 @@ struct wr_ctx {
     // pinned host
     double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index
     uint8_t* h_planes = nullptr; size_t h_planes_bytes = 0;
+    uint16_t* d_hist = nullptr; uint16_t* h_hist = nullptr; size_t hist_elems = 0;  // per-block byte histograms, all planes
     // host coded-stream staging, one per plane
     std::vector<uint8_t> enc_buf[WR_NLAYMAX];
     hipEvent_t ev_plane[WR_NLAYMAX], ev_copy[WR_NLAYMAX], ev_a, ev_b, ev_c, ev_d;
@@ -124,6 +125,18 @@ int ensure_host_planes(wr_ctx* c, size_t bytes)
     c->h_planes = nullptr; c->h_planes_bytes = 0;
     HIPCHK(hipHostMalloc(&c->h_planes, bytes, hipHostMallocDefault));
     c->h_planes_bytes = bytes;
+    return WR_OK;
+}
+
+int ensure_hist(wr_ctx* c, size_t elems)
+{
+    if (c->hist_elems >= elems) return WR_OK;
+    if (c->d_hist) HIPCHK(hipFree(c->d_hist));
+    if (c->h_hist) HIPCHK(hipHostFree(c->h_hist));
+    c->d_hist = nullptr; c->h_hist = nullptr; c->hist_elems = 0;
+    HIPCHK(hipMalloc(&c->d_hist, elems * sizeof(uint16_t)));
+    HIPCHK(hipHostMalloc(&c->h_hist, elems * sizeof(uint16_t), hipHostMallocDefault));
+    c->hist_elems = elems;
     return WR_OK;
 }
 
@@ -325,7 +338,7 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipStreamSynchronize(c->copy);
     (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field); (void)hipFree(c->d_lowbuf); (void)hipFree(c->d_cutoff);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
-    (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_planes);
+    (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_planes); (void)hipFree(c->d_hist); (void)hipHostFree(c->h_hist);
     for (int i = 0; i < WR_NLAYMAX; i++) { (void)hipEventDestroy(c->ev_plane[i]); (void)hipEventDestroy(c->ev_copy[i]); }
     (void)hipEventDestroy(c->ev_a); (void)hipEventDestroy(c->ev_b);
     (void)hipEventDestroy(c->ev_c); (void)hipEventDestroy(c->ev_d);
@@ -627,6 +640,10 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     // device + pinned plane buffers for the worst case are grown lazily, plane by plane
     if (int rc = ensure_planes(c, pitch * WR_NLAYMAX)) return rc;
     if (int rc = ensure_host_planes(c, pitch * WR_NLAYMAX)) return rc;
+    // per-60000-symbol-block byte histograms, counted on the GPU next to the quantizer and shipped
+    // with the plane, so that the host coder starts every block with its model ready
+    const size_t hist_per_plane = (n / wrrc::kBlock + 1) * 256;
+    if (int rc = ensure_hist(c, hist_per_plane * WR_NLAYMAX)) return rc;
 
     std::vector<std::thread> workers;
     size_t lens[WR_NLAYMAX] = {0};
@@ -639,6 +656,9 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     auto on_plane = [&](unsigned l, bool) -> int {
         // plane l: device -> pinned host on the copy stream, then its own coder thread
         HIPCHK(hipStreamWaitEvent(c->copy, c->ev_plane[l], 0));
+        wrk::block_histograms(c->d_planes + l * pitch, n, c->d_hist + l * hist_per_plane, c->copy);
+        HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, c->d_hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
+                              hipMemcpyDeviceToHost, c->copy));
         HIPCHK(hipMemcpyAsync(c->h_planes + l * pitch, c->d_planes + l * pitch, n, hipMemcpyDeviceToHost, c->copy));
         HIPCHK(hipEventRecord(c->ev_copy[l], c->copy));
         c->enc_buf[l].resize(wrrc::encode_bound(n));
@@ -648,7 +668,7 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
             sem.acquire();
             const double t = now();
             const uint8_t* q = c->h_planes + l * pitch;
-            lens[l] = wrrc::encode_plane(q, n, c->enc_buf[l].data(), nullptr);
+            lens[l] = wrrc::encode_plane(q, n, c->enc_buf[l].data(), c->h_hist + l * hist_per_plane);
             coder_s[l] = now() - t;
             sem.release();
             if (verbose()) {  // wrappers.cpp:401-409, 430
