@@ -131,9 +131,10 @@ def main():
             dist.all_reduce(t)
             torch.cuda.synchronize()
 
-    # one host pipeline (context + work buffers) per tolerance setting: the settings of a step are
-    # independent jobs and run concurrently on the one GPU; their device phases serialise inside
-    # the library, their host range coding overlaps
+    # One lane per tolerance setting (the settings of a step are independent jobs and run
+    # concurrently on the one GPU).  A lane is a two-stage pipeline -- encoder context and decoder
+    # context, two coded-stream buffers in between -- so that step k+1's encode overlaps step k's
+    # decode: device phases of all contexts serialise inside the library, host range coding overlaps.
     import threading
     ctx = api.Context(dev_index)
     shape = (n, n, n)
@@ -144,35 +145,61 @@ def main():
     _, cap = api.setup_wr(n, n, n)
     lanes = []
     for i, tol in enumerate(tols):
-        c = ctx if i == 0 else api.Context(dev_index)
-        lanes.append(dict(tol=tol, ctx=c, work=c.alloc(nelem * 8), data=np.empty(cap, dtype=np.uint8)))
+        ce = ctx if i == 0 else api.Context(dev_index)
+        cd = api.Context(dev_index)
+        lanes.append(dict(tol=tol, enc=ce, dec=cd, work=ce.alloc(nelem * 8), rec=cd.alloc(nelem * 8),
+                          data=[np.empty(cap, dtype=np.uint8) for _ in range(2)]))
 
     stats = {t: {} for t in tols}
     acc = {"fwd_ms": [], "inv_ms": [], "quant_ms": [], "dequant_ms": [], "enc_s": [], "dec_s": [],
            "enc_rc_s": [], "dec_rc_s": [], "enc_gpu_s": [], "dec_gpu_s": []}
-
     lock = threading.Lock()
     errors = []
 
-    def job(ln, record):
-        try:
-            c, tol = ln["ctx"], ln["tol"]
-            c.copy(ln["work"], orig, nelem * 8)
-            enc, te = c.encode(ln["work"], shape, tol, out=ln["data"])
-            td = c.decode(ln["work"], shape, enc)
-            if record:
-                with lock:
-                    acc["fwd_ms"].append(te["transform_ms"]); acc["inv_ms"].append(td["transform_ms"])
-                    acc["quant_ms"].append(te["quant_ms"]); acc["dequant_ms"].append(td["quant_ms"])
-                    acc["enc_s"].append(te["total"]); acc["dec_s"].append(td["total"])
-                    acc["enc_rc_s"].append(te["rangecoder"]); acc["dec_rc_s"].append(td["rangecoder"])
-                    acc["enc_gpu_s"].append(te["gpu"]); acc["dec_gpu_s"].append(td["gpu"])
-                    stats[tol] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"]}
-        except Exception as exc:  # surfaced after the join
-            errors.append(exc)
+    def run_steps(nsteps, record):
+        """nsteps steps of every lane; returns when all of them have been encoded AND decoded."""
+        ths = []
+        for ln in lanes:
+            coded = [threading.Semaphore(0), threading.Semaphore(0)]  # slot holds a coded field
+            free = [threading.Semaphore(1), threading.Semaphore(1)]   # slot may be overwritten
+            box = [None, None]
 
-    def step(record):
-        ths = [threading.Thread(target=job, args=(ln, record)) for ln in lanes]
+            def encoder(ln=ln, coded=coded, free=free, box=box):
+                try:
+                    for k in range(nsteps):
+                        free[k & 1].acquire()
+                        ln["enc"].copy(ln["work"], orig, nelem * 8)
+                        enc, te = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][k & 1])
+                        box[k & 1] = (enc, te)
+                        coded[k & 1].release()
+                except Exception as exc:
+                    errors.append(exc)
+                    for sem in coded:
+                        sem.release()
+
+            def decoder(ln=ln, coded=coded, free=free, box=box):
+                try:
+                    for k in range(nsteps):
+                        coded[k & 1].acquire()
+                        if errors:
+                            return
+                        enc, te = box[k & 1]
+                        td = ln["dec"].decode(ln["rec"], shape, enc)
+                        free[k & 1].release()
+                        if record:
+                            with lock:
+                                acc["fwd_ms"].append(te["transform_ms"]); acc["inv_ms"].append(td["transform_ms"])
+                                acc["quant_ms"].append(te["quant_ms"]); acc["dequant_ms"].append(td["quant_ms"])
+                                acc["enc_s"].append(te["total"]); acc["dec_s"].append(td["total"])
+                                acc["enc_rc_s"].append(te["rangecoder"]); acc["dec_rc_s"].append(td["rangecoder"])
+                                acc["enc_gpu_s"].append(te["gpu"]); acc["dec_gpu_s"].append(td["gpu"])
+                                stats[ln["tol"]] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"]}
+                except Exception as exc:
+                    errors.append(exc)
+                    for sem in free:
+                        sem.release()
+
+            ths += [threading.Thread(target=encoder), threading.Thread(target=decoder)]
         for th in ths:
             th.start()
         for th in ths:
@@ -180,12 +207,11 @@ def main():
         if errors:
             raise errors[0]
 
-    for _ in range(args.warmup):
-        step(False)
+    if args.warmup:
+        run_steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -194,7 +220,7 @@ def main():
         dt = float(t.item())
 
     # accuracy of the last reconstruction (tols[-1]) against the original, on the device
-    diff, amax = lanes[-1]["ctx"].linf(orig, lanes[-1]["work"], nelem)
+    diff, amax = lanes[-1]["dec"].linf(orig, lanes[-1]["rec"], nelem)
     linf_rel = diff / amax
 
     mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
@@ -213,7 +239,7 @@ def main():
             "config": {"workload": "single %d^3 fp64 field per GPU, tol=%s (BASELINE configs[2])"
                                    % (n, " and ".join("%g" % t for t in tols)),
                        "field_shards": world, "range_coder_threads": args.threads,
-                       "concurrent_jobs_per_gpu": len(tols),
+                       "concurrent_jobs_per_gpu": len(tols), "pipeline": "encode(k+1) overlaps decode(k)",
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(n),
@@ -234,7 +260,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     for ln in lanes:
-        ln["ctx"].close()
+        ln["dec"].close()
+        ln["enc"].close()
 
 
 if __name__ == "__main__":
