@@ -236,8 +236,9 @@ def main():
             "value": round(total_mb / dt, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "single %d^3 fp64 field per GPU, tol=%s (BASELINE configs[2])"
-                                   % (n, " and ".join("%g" % t for t in tols)),
+            "config": {"workload": "single %d^3 fp64 field per GPU, tol=%s (%s)"
+                                   % (n, " and ".join("%g" % t for t in tols),
+                                      "BASELINE configs[2]" if n == 1024 else "BASELINE configs[1]/[3] shape" if n == 512 else "parity-size run"),
                        "field_shards": world, "range_coder_threads": args.threads,
                        "concurrent_jobs_per_gpu": len(tols), "pipeline": "encode(k+1) overlaps decode(k)",
                        "planes": {("%g" % t): stats[t] for t in tols}},
