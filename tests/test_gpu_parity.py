@@ -377,3 +377,39 @@ def test_api_error_paths(ctx, api):
     again, _ = ctx.encode(buf, f.shape, 1e-6)
     assert np.array_equal(again["data"], enc["data"])
     buf.free()
+
+
+def test_concurrent_contexts_are_bit_exact(api, oracle):
+    """Several contexts on one GPU driven from concurrent host threads (what bench.py and the FluSI
+    front-end do): device phases serialise inside the library, host coding overlaps; every stream
+    and reconstruction must still equal the oracle's."""
+    import threading
+    jobs = [((64, 64, 64), 1e-7, 12345), ((96, 64, 64), 1e-4, 7), ((37, 21, 13), 1e-6, 9), ((128, 64, 80), 1e-5, 3)]
+    want = {}
+    for shape, tol, seed in jobs:
+        f = synth.field(*shape, seed=seed)
+        e = oracle.encode(f, tol)
+        want[(shape, tol, seed)] = (f, e, oracle.decode(e, f.shape))
+    errors = []
+
+    def worker(job):
+        try:
+            f, e, rec = want[job]
+            with api.Context(0) as c:
+                for _ in range(3):
+                    buf = c.to_device(f)
+                    enc, _ = c.encode(buf, f.shape, job[1])
+                    assert np.array_equal(enc["data"], e["data"]) and enc["len_enc_vec"] == e["len_enc_vec"]
+                    enc["data"] = enc["data"].copy()
+                    c.decode(buf, f.shape, enc)
+                    assert bits_equal(buf.download(np.float64, f.size), rec)
+                    buf.free()
+        except Exception as exc:  # noqa: BLE001
+            errors.append((job, exc))
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors

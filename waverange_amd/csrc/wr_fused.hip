@@ -23,6 +23,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 #pragma clang fp contract(off)
 
 namespace wrk {
@@ -698,11 +700,8 @@ extern "C" unsigned long long* wr_stamp_buffer(size_t nwaves)
 
 void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        attr_set = true;
-    }
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES); });
     const size_t d_sy = (size_t)nx, d_sz = (size_t)nx * ny;
     const double* in = src;
     size_t in_sy = d_sy, in_sz = d_sz;
@@ -731,11 +730,8 @@ void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx,
 
 void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_inv_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV);
-        attr_set = true;
-    }
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_inv_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV); });
     const size_t f_sy = (size_t)nx, f_sz = (size_t)nx * ny;
     // compact reconstruction buffers: C1 = (n/2)^3, C2 = (n/4)^3, C3 = (n/8)^3, laid out as in the forward pass
     double* cbuf[4] = {nullptr, lowbuf, nullptr, nullptr};
