@@ -9,7 +9,7 @@ from waverange_amd import synth
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(64, 64, 64), (13, 9, 7), (37, 21, 13), (33, 5, 1), (2, 2, 2), (3, 3, 3), (17, 1, 1),
-          (9, 1, 40), (1, 4, 1), (100, 3, 2), (130, 70, 34), (256, 8, 4), (1030, 6, 5),
+          (9, 1, 40), (1, 4, 1), (100, 3, 2), (130, 70, 34), (256, 8, 4), (1030, 6, 5), (257, 129, 65),
           # multiples of 16 and >= 64: the fused single-pass-per-level kernels
           (128, 64, 80), (96, 64, 64), (64, 128, 64), (272, 96, 64), (64, 64, 144)]
 
