@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
-    ap.add_argument("--cpu-size", type=int, default=320)
+    ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
     args = ap.parse_args()
@@ -254,6 +254,12 @@ def main():
                        "device_only_MBps": round(2 * field_mb / max(1e-9, mean(acc["enc_gpu_s"]) + mean(acc["dec_gpu_s"])), 1)},
             "accuracy": {"tol": tols[-1], "linf_rel": linf_rel},
         }
+        try:  # peak resident host memory of this rank (pinned staging included)
+            with open("/proc/self/status") as fh:
+                hwm = [l for l in fh if l.startswith("VmHWM")][0].split()
+            out["host_peak_rss_gib"] = round(int(hwm[1]) / 2 ** 20, 2)
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols)
         print(json.dumps(out), flush=True)

@@ -86,10 +86,10 @@ struct wr_ctx {
     unsigned long long* d_idx = nullptr;
     // pinned host
     double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index
-    uint8_t* h_planes = nullptr; size_t h_planes_bytes = 0;
+    uint8_t* h_plane[WR_NLAYMAX] = {nullptr}; size_t h_plane_bytes[WR_NLAYMAX] = {0};  // pinned, one per plane, on demand
     uint16_t* d_hist = nullptr; uint16_t* h_hist = nullptr; size_t hist_elems = 0;  // per-block byte histograms, all planes
     // host coded-stream staging, one per plane
-    std::vector<uint8_t> enc_buf[WR_NLAYMAX];
+    uint8_t* enc_buf[WR_NLAYMAX] = {nullptr}; size_t enc_buf_bytes[WR_NLAYMAX] = {0};  // malloc'd: only coded bytes get touched
     hipEvent_t ev_plane[WR_NLAYMAX], ev_copy[WR_NLAYMAX], ev_a, ev_b, ev_c, ev_d;
     std::mutex mu;
 };
@@ -118,14 +118,25 @@ int ensure_planes(wr_ctx* c, size_t bytes)
     return WR_OK;
 }
 
-int ensure_host_planes(wr_ctx* c, size_t bytes)
+// pinned staging of plane l, allocated the first time a field needs that many planes (a 1024^3
+// field at tol 1e-3 needs 3 GiB here, not 8)
+int ensure_host_plane(wr_ctx* c, int l, size_t bytes)
 {
-    if (c->h_planes_bytes >= bytes) return WR_OK;
-    if (c->h_planes) HIPCHK(hipHostFree(c->h_planes));
-    c->h_planes = nullptr; c->h_planes_bytes = 0;
-    HIPCHK(hipHostMalloc(&c->h_planes, bytes, hipHostMallocDefault));
-    c->h_planes_bytes = bytes;
+    if (c->h_plane_bytes[l] >= bytes) return WR_OK;
+    if (c->h_plane[l]) HIPCHK(hipHostFree(c->h_plane[l]));
+    c->h_plane[l] = nullptr; c->h_plane_bytes[l] = 0;
+    HIPCHK(hipHostMalloc(&c->h_plane[l], bytes, hipHostMallocDefault));
+    c->h_plane_bytes[l] = bytes;
     return WR_OK;
+}
+
+int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
+{
+    if (c->enc_buf_bytes[l] >= bytes) return WR_OK;
+    free(c->enc_buf[l]);
+    c->enc_buf[l] = static_cast<uint8_t*>(malloc(bytes));
+    c->enc_buf_bytes[l] = c->enc_buf[l] ? bytes : 0;
+    return c->enc_buf[l] ? WR_OK : fail(WR_ERR_ARG, "out of host memory for the coded stream");
 }
 
 int ensure_hist(wr_ctx* c, size_t elems)
@@ -338,7 +349,8 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipStreamSynchronize(c->copy);
     (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field); (void)hipFree(c->d_lowbuf); (void)hipFree(c->d_cutoff);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
-    (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_planes); (void)hipFree(c->d_hist); (void)hipHostFree(c->h_hist);
+    (void)hipHostFree(c->h_result); (void)hipFree(c->d_hist); (void)hipHostFree(c->h_hist);
+    for (int l = 0; l < WR_NLAYMAX; l++) { (void)hipHostFree(c->h_plane[l]); free(c->enc_buf[l]); }
     for (int i = 0; i < WR_NLAYMAX; i++) { (void)hipEventDestroy(c->ev_plane[i]); (void)hipEventDestroy(c->ev_copy[i]); }
     (void)hipEventDestroy(c->ev_a); (void)hipEventDestroy(c->ev_b);
     (void)hipEventDestroy(c->ev_c); (void)hipEventDestroy(c->ev_d);
@@ -639,7 +651,6 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     wr_timings local; memset(&local, 0, sizeof local);
     // device + pinned plane buffers for the worst case are grown lazily, plane by plane
     if (int rc = ensure_planes(c, pitch * WR_NLAYMAX)) return rc;
-    if (int rc = ensure_host_planes(c, pitch * WR_NLAYMAX)) return rc;
     // per-60000-symbol-block byte histograms, counted on the GPU next to the quantizer and shipped
     // with the plane, so that the host coder starts every block with its model ready
     const size_t hist_per_plane = (n / wrrc::kBlock + 1) * 256;
@@ -659,16 +670,17 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
         wrk::block_histograms(c->d_planes + l * pitch, n, c->d_hist + l * hist_per_plane, c->copy);
         HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, c->d_hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
                               hipMemcpyDeviceToHost, c->copy));
-        HIPCHK(hipMemcpyAsync(c->h_planes + l * pitch, c->d_planes + l * pitch, n, hipMemcpyDeviceToHost, c->copy));
+        if (int rc = ensure_host_plane(c, (int)l, pitch)) return rc;
+        if (int rc = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_plane[l], c->d_planes + l * pitch, n, hipMemcpyDeviceToHost, c->copy));
         HIPCHK(hipEventRecord(c->ev_copy[l], c->copy));
-        c->enc_buf[l].resize(wrrc::encode_bound(n));
         workers.emplace_back([&, l]() {
             (void)hipSetDevice(dev);
             (void)hipEventSynchronize(c->ev_copy[l]);
             sem.acquire();
             const double t = now();
-            const uint8_t* q = c->h_planes + l * pitch;
-            lens[l] = wrrc::encode_plane(q, n, c->enc_buf[l].data(), c->h_hist + l * hist_per_plane);
+            const uint8_t* q = c->h_plane[l];
+            lens[l] = wrrc::encode_plane(q, n, c->enc_buf[l], c->h_hist + l * hist_per_plane);
             coder_s[l] = now() - t;
             sem.release();
             if (verbose()) {  // wrappers.cpp:401-409, 430
@@ -697,7 +709,7 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     size_t total = 0;
     for (unsigned l = 0; l < info->nlay; l++) {
         if (total + lens[l] > cap) return fail(WR_ERR_OVERFLOW, "Error: encoded array is too large. Use larger SAFETY_BUFFER_FACTOR");
-        memcpy(data_enc + total, c->enc_buf[l].data(), lens[l]);
+        memcpy(data_enc + total, c->enc_buf[l], lens[l]);
         info->len_enc_vec[l] = lens[l];
         total += lens[l];
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
@@ -733,7 +745,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     if (nlay < 1 || nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
     if (verbose()) printf("Range decoding...\n");
     if (int rc = ensure_planes(c, pitch * nlay)) return rc;
-    if (int rc = ensure_host_planes(c, pitch * nlay)) return rc;
+    for (int l = 0; l < nlay; l++) if (int rc = ensure_host_plane(c, l, pitch)) return rc;
     if (int rc = ensure_scratch(c, n)) return rc;
 
     size_t off[WR_NLAYMAX + 1] = {0};
@@ -747,7 +759,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
         workers.emplace_back([&, l]() {
             sem.acquire();
             const double t = now();
-            got[l] = wrrc::decode_plane(data_enc + off[l], info->len_enc_vec[l], c->h_planes + l * pitch, n);
+            got[l] = wrrc::decode_plane(data_enc + off[l], info->len_enc_vec[l], c->h_plane[l], n);
             coder_s[l] = now() - t;
             sem.release();
         });
@@ -762,7 +774,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     const double t_coded = now();
     if (verbose()) {  // wrappers.cpp:489, 503-510
         for (int l = 0; l < nlay; l++) {
-            const uint8_t* q = c->h_planes + l * pitch;
+            const uint8_t* q = c->h_plane[l];
             unsigned lo = q[0], hi = q[0];
             for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
             printf("ilay=%d\nimin=%u imax=%u med=%g\n", l, lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l]);
@@ -776,7 +788,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     {
         std::lock_guard<std::mutex> gpu(g_gpu_phase);
         for (int l = 0; l < nlay; l++)  // planes: pinned host -> device
-            HIPCHK(hipMemcpyAsync(c->d_planes + l * pitch, c->h_planes + l * pitch, n, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->d_planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, c->stream));
         if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
