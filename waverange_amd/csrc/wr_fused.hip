@@ -9,8 +9,9 @@
 //     the previous pair is being computed; at the domain edges the halo is filled by
 //     whole-sample mirroring, which reproduces the reference's doubled boundary terms bit
 //     for bit (c*(v+v) == (2c)*v), so the tile code has no edge branches;
-//   * x lifting: every (row, x-pair) recomputes its 4-stage chain from 5 raw pairs in LDS
-//     (no barrier between stages), writes [low | high] halves of the row to a second buffer;
+//   * x lifting: every lane recomputes the 4-stage chain of two adjacent x-pairs of a row from 6
+//     raw pairs in LDS (no barrier between stages; 14 lifting steps for the two pairs), and
+//     writes the [low | high] halves of the row to a second buffer;
 //   * y lifting: the same recomputation down the columns, 11 rows -> two y-pairs, result in
 //     registers: 8 values (LL, HL, LH, HH of both pairs) per plane per thread;
 //   * z lifting: streaming register pipeline (as k_stream), 5 doubles of state per point;
@@ -87,24 +88,8 @@ __device__ inline int mirror(int v, int n)
     return v < 0 ? 0 : (v >= n ? n - 1 : v);  // far outside (partial tiles): any valid index
 }
 
-// forward lifting of the centre pair from s[-2..2], d[-2..1]  (waveletcdf97_3d.c:112-132)
-__device__ inline void lift_fwd_center(const double s[5], const double d[4], double& lo, double& hi)
-{
-    const double d1a = d[0] + WR_ALPHA * (s[1] + s[0]);
-    const double d1b = d[1] + WR_ALPHA * (s[2] + s[1]);
-    const double d1c = d[2] + WR_ALPHA * (s[3] + s[2]);
-    const double d1d = d[3] + WR_ALPHA * (s[4] + s[3]);
-    const double s1b = s[1] + WR_BETA * (d1b + d1a);
-    const double s1c = s[2] + WR_BETA * (d1c + d1b);
-    const double s1d = s[3] + WR_BETA * (d1d + d1c);
-    const double d2b = d1b + WR_GAMMA * (s1c + s1b);
-    const double d2c = d1c + WR_GAMMA * (s1d + s1c);
-    const double s2c = s1c + WR_DELTA * (d2c + d2b);
-    lo = s2c * WR_ZETA;
-    hi = d2c * WR_IZETA;
-}
-
-// forward lifting of two adjacent pairs from s[-2..3], d[-2..2]: 14 lifting steps instead of 20
+// forward lifting of two adjacent pairs from s[-2..3], d[-2..2]  (waveletcdf97_3d.c:112-132):
+// 14 lifting steps instead of 2 x 10 for two separately recomputed pairs
 __device__ inline void lift_fwd_two(const double s[6], const double d[5], double& lo0, double& hi0, double& lo1,
                                     double& hi1)
 {
@@ -184,31 +169,20 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             }
         }
     };
-#ifdef WR_NOPATCH
-    const bool left_edge = false, right_edge = false;  // timing experiment only: wrong results at the x edges
-#else
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
-#endif
     const int iL = m1 - 1 - px0;  // local index of the last x-pair of the domain (right-edge tiles)
 
-    // x lifting of every staged row of plane p -> xl.  Wave w owns rows w, w+NWAVE, ...
+    // x lifting of every staged row of plane p -> xl.  Wave w owns rows 2(w + NWAVE k) and the next.
     // First the mirrored x halo of those rows is patched (edge tiles only), THEN all rows are
     // read: with no LDS store between the reads of consecutive rows the compiler can issue the
     // next row's ds_read_b128s while the current row's lifting chain is still executing.
-    constexpr int XR = (RROWS + NWAVE - 1) / NWAVE;  // rows per wave (5)
-    constexpr int XFULL = RROWS / NWAVE;             // rounds in which every wave has a row (4)
     auto xlift = [&](int p) {
         double2* rp = raw + p * NCHUNK;
         if (left_edge | right_edge) {
             // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
             // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3])
-#ifdef WR_XLIFT1
-            if (lane < 2 * XR) {
-                const int row = w + NWAVE * (lane >> 1);
-#else
             if (lane < 4 * ((RROWS + 2 * NWAVE - 1) / (2 * NWAVE))) {
                 const int row = 2 * (w + NWAVE * (lane >> 2)) + ((lane >> 1) & 1);
-#endif
                 if (row < RROWS) {
                     double2* e = rp + row * RX;
                     if (left_edge) e[lane & 1] = (lane & 1) ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
@@ -219,21 +193,6 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                 }
             }
         }
-#ifdef WR_XLIFT1
-        auto one_row = [&](int row) {
-            const double2* r = rp + row * RX + lane;
-            const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
-            const double s[5] = {v0.x, v1.x, v2.x, v3.x, v4.x};
-            const double d[4] = {v0.y, v1.y, v2.y, v3.y};
-            double lo, hi;
-            lift_fwd_center(s, d, lo, hi);
-            xl[row * (2 * TXP) + lane] = lo;
-            xl[row * (2 * TXP) + TXP + lane] = hi;
-        };
-#pragma unroll
-        for (int k = 0; k < XFULL; k++) one_row(w + NWAVE * k);
-        if (XR > XFULL && w + NWAVE * XFULL < RROWS) one_row(w + NWAVE * XFULL);
-#else
         // two adjacent x-pairs per lane (14 lifting steps instead of 20): a wave covers two rows
         // per round, lanes 0-31 the first, lanes 32-63 the second
         const int half = lane >> 5, jp = (lane & 31) * 2;  // first of this lane's two x-pairs
@@ -253,7 +212,6 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             const int row = 2 * (w + NWAVE * k) + half;
             if (row < RROWS) two_rows(row);
         }
-#endif
     };
     // y lifting of this thread's two y-pairs (2w, 2w+1) for its two x columns:
     // out[4*yp + {0,1,2,3}] = {LL, HL, LH, HH} of y-pair yp
@@ -379,28 +337,7 @@ constexpr size_t LDS_INV = (size_t)3 * NCI * 16 + (size_t)INWAVE * 2 * (2 * HX) 
 __device__ inline int mirror_s(int k, int M) { if (k < 0) k = -k; if (k >= M) k = 2 * M - 1 - k; return k < 0 ? 0 : (k >= M ? M - 1 : k); }
 __device__ inline int mirror_d(int k, int M) { if (k < 0) k = -k - 1; if (k >= M) k = 2 * M - 2 - k; return k < 0 ? 0 : (k >= M ? M - 1 : k); }
 
-// inverse lifting of the centre pair from s[-1..2], d[-2..2] (unscaled inputs)  (:312-337)
-__device__ inline void lift_inv_center(const double sr[4], const double dr[5], double& even, double& odd)
-{
-    double s[4], d[5];
-#pragma unroll
-    for (int k = 0; k < 4; k++) s[k] = sr[k] * WR_IZETA;
-#pragma unroll
-    for (int k = 0; k < 5; k++) d[k] = dr[k] * WR_ZETA;
-    const double s1a = s[0] - WR_DELTA * (d[1] + d[0]);
-    const double s1b = s[1] - WR_DELTA * (d[2] + d[1]);
-    const double s1c = s[2] - WR_DELTA * (d[3] + d[2]);
-    const double s1d = s[3] - WR_DELTA * (d[4] + d[3]);
-    const double d1a = d[1] - WR_GAMMA * (s1b + s1a);
-    const double d1b = d[2] - WR_GAMMA * (s1c + s1b);
-    const double d1c = d[3] - WR_GAMMA * (s1d + s1c);
-    const double s2b = s1b - WR_BETA * (d1b + d1a);
-    const double s2c = s1c - WR_BETA * (d1c + d1b);
-    even = s2b;
-    odd = d1b - WR_ALPHA * (s2c + s2b);
-}
-
-// two adjacent pairs from s[-1..3], d[-2..3]: 14 lifting steps
+// inverse lifting of two adjacent pairs from s[-1..3], d[-2..3] (unscaled inputs)  (:312-337): 14 lifting steps
 __device__ inline void lift_inv_two(const double sr[5], const double dr[6], double out[4])
 {
     double s[5], d[6];
@@ -484,11 +421,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         }
     };
 
-#ifdef WR_NOPATCH
-    const bool left_edge = false, right_edge = false;
-#else
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
-#endif
     const int iL = m1 - 1 - px0;
     double* ybw = yb + w * (2 * 2 * HX);  // this wave's two rows of [xlow 68 | xhigh 68]
     const int J = 2 * w;                   // first of this wave's two local y-pairs
@@ -505,21 +438,6 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
             if (lane & 1) { r[iL + 3] = r[iL + 2]; r[iL + 4] = r[iL + 1]; }            // s[m] = s[m-1], s[m+1] = s[m-2]
             else { r[HX + iL + 3] = r[HX + iL + 1]; r[HX + iL + 4] = r[HX + iL]; }     // d[m] = d[m-2], d[m+1] = d[m-3]
         }
-#ifdef WR_XINV1
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const double* row = ybw + r * (2 * HX);
-            const double sr[4] = {row[lane + 1], row[lane + 2], row[lane + 3], row[lane + 4]};
-            const double dr[5] = {row[HX + lane], row[HX + lane + 1], row[HX + lane + 2], row[HX + lane + 3],
-                                  row[HX + lane + 4]};
-            double ev, od;
-            lift_inv_center(sr, dr, ev, od);
-            const int y = yrow0 + r;
-            if (px0 + lane < m1 && y < n2)
-                *reinterpret_cast<double2*>(out + (size_t)zplane * o_sz + (size_t)y * o_sy + 2 * (px0 + lane)) =
-                    make_double2(ev, od);
-        }
-#else
         {   // two adjacent x-pairs per lane (14 lifting steps instead of 20): lanes 0-31 take the
             // first of the two rows, lanes 32-63 the second
             const int r = lane >> 5, i = (lane & 31) * 2;
@@ -537,7 +455,6 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                 if (px0 + i + 1 < m1) *reinterpret_cast<double2*>(dstp + 2) = make_double2(o[2], o[3]);
             }
         }
-#endif
     };
     // y + x stages of the z-plane held in zb
     auto yxstage = [&](int zplane) {
