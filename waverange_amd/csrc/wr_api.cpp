@@ -706,15 +706,24 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     for (auto& w : workers) w.join();
     if (rc) return rc;
     const double t_coded = now();
-    size_t total = 0;
+    // concatenate the plane streams (wrappers.cpp:412-427); gigabytes at 1024^3, so one copier per plane
+    size_t total = 0, offs[WR_NLAYMAX] = {0};
     for (unsigned l = 0; l < info->nlay; l++) {
-        if (total + lens[l] > cap) return fail(WR_ERR_OVERFLOW, "Error: encoded array is too large. Use larger SAFETY_BUFFER_FACTOR");
-        memcpy(data_enc + total, c->enc_buf[l], lens[l]);
-        info->len_enc_vec[l] = lens[l];
+        offs[l] = total;
         total += lens[l];
+        info->len_enc_vec[l] = lens[l];
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
-        if (verbose()) fputs(logs[l].c_str(), stdout);
     }
+    if (total > cap) return fail(WR_ERR_OVERFLOW, "Error: encoded array is too large. Use larger SAFETY_BUFFER_FACTOR");
+    {
+        std::vector<std::thread> copiers;
+        for (unsigned l = 1; l < info->nlay; l++)
+            copiers.emplace_back([&, l]() { memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]); });
+        if (info->nlay) memcpy(data_enc, c->enc_buf[0], lens[0]);
+        for (auto& t : copiers) t.join();
+    }
+    if (verbose())
+        for (unsigned l = 0; l < info->nlay; l++) fputs(logs[l].c_str(), stdout);
     info->ntot_enc = total;
     local.total = now() - t0;
     local.gpu = t_gpu_done - t0;
