@@ -350,9 +350,14 @@ def test_api_error_paths(ctx, api):
     small = np.empty(enc["ntot_enc"] // 2, dtype=np.uint8)
     with pytest.raises(api.WaveRangeError, match="encoded array is too large"):
         ctx.encode(buf, f.shape, 1e-6, out=small)
-    # truncated stream: plane does not decode to nx*ny*nz symbols -> WR_ERR_STREAM
+    # truncated last plane (header and buffer agree on the shorter length): the plane does not decode
+    # to nx*ny*nz symbols -> WR_ERR_STREAM.  (A buffer shorter than ntot_enc says would be a caller bug
+    # the library cannot see.)
     bad = dict(enc)
-    bad["data"] = enc["data"][: enc["ntot_enc"] // 2].copy()
+    bad["len_enc_vec"] = list(enc["len_enc_vec"])
+    bad["len_enc_vec"][-1] //= 2
+    bad["ntot_enc"] = sum(bad["len_enc_vec"])
+    bad["data"] = enc["data"][: bad["ntot_enc"]].copy()
     with pytest.raises(api.WaveRangeError):
         ctx.decode(buf, f.shape, bad)
     # corrupted bytes in the middle of a plane: must not crash; either an error or a wrong field
