@@ -257,8 +257,11 @@ inline size_t decode_symbols(Dec& d, uint8_t* dst, size_t room, uint32_t bs, con
             range <<= 8;
         }
         const uint32_t help = range / tot;
-        uint32_t cf = low / help;
-        if (cf >= tot) cf = tot - 1;
+        // low < range = help*tot + (range % tot)  =>  cf < tot + tot/help <= tot + tot^2/2^23 < tot + 430
+        // for tot <= 60000.  rangecod.c:317 clamps cf to tot-1, which only ever selects the largest
+        // symbol present; the lookup table is padded with that symbol instead (no clamp on the
+        // per-symbol dependency chain: +5 % decode speed).
+        const uint32_t cf = low / help;
         const uint32_t c = lookup[cf];
         const uint32_t t = help * tab[c].lt;
         low -= t;
@@ -276,7 +279,8 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
     // wrappers.cpp:153-224
     Dec d(in, len);
     size_t produced = 0;
-    std::vector<uint8_t> lookup(65536 * 2);
+    constexpr uint32_t kPad = 512;
+    std::vector<uint8_t> lookup(kBlock + kPad);
     while (d.culfreq(2)) {
         d.update(1, 1, 2);
         SymEntry tab[256];
@@ -288,9 +292,10 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
             bs += c;
             if (c) top_sym = (uint32_t)b;
         }
-        if (bs > 65535u * 2) return (size_t)-1;  // not a WaveRange stream (blocks are <= 60000)
+        if (bs > kBlock) return (size_t)-1;  // not a WaveRange stream (blocks hold at most 60000 symbols, defs.h:36)
         for (int b = 0; b < 256; b++)
             if (tab[b].sy) memset(lookup.data() + tab[b].lt, b, tab[b].sy);
+        memset(lookup.data() + bs, (int)top_sym, kPad);  // see decode_symbols
         const size_t room = produced < n ? n - produced : 0;
         uint8_t* dst = sym + (produced < n ? produced : n);
         if (bs == kBlock) decode_symbols<kBlock>(d, dst, room, bs, tab, lookup.data(), top_sym);
