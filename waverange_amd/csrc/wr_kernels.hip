@@ -61,83 +61,63 @@ __global__ __launch_bounds__(256) void k_line_x(double* __restrict__ X, int n, i
     const long long line0 = (long long)blockIdx.x * R;
     const int tid = threadIdx.x, nt = blockDim.x;
     const bool odd = n & 1;
+    int rows = R;  // lines of this workgroup that exist
+    if (line0 + rows > nlines) rows = (int)(nlines - line0);
 
-    // ---- load (coalesced over the line), de-interleave (fwd) or scale (inv)
-    for (int e = tid; e < R * n; e += nt) {
-        int r = e / n, j = e - r * n;
-        long long line = line0 + r;
-        if (line >= nlines) break;
-        size_t base = (size_t)(line % n2) * sy + (size_t)(line / n2) * sz;
-        double v = X[base + j];
-        if (!INV) {
-            if (j & 1) D[r * mp + (j >> 1)] = v; else S[r * mp + (j >> 1)] = v;
-        } else {
-            if (j < m) S[r * mp + j] = v * WR_IZETA; else D[r * mp + (j - m)] = v * WR_ZETA;
+    // ---- load (coalesced over the line), de-interleave (fwd) or scale (inv).  Loops are
+    // (line, position) nests: no per-element division.
+    for (int r = 0; r < rows; r++) {
+        const long long line = line0 + r;
+        const double* src = X + (size_t)(line % n2) * sy + (size_t)(line / n2) * sz;
+        double* s = S + r * mp; double* d = D + r * mp;
+        for (int j = tid; j < n; j += nt) {
+            const double v = src[j];
+            if (!INV) { if (j & 1) d[j >> 1] = v; else s[j >> 1] = v; }
+            else { if (j < m) s[j] = v * WR_IZETA; else d[j - m] = v * WR_ZETA; }
         }
     }
     __syncthreads();
     if (odd) {
         // fwd: synthesise the missing last odd sample (:109); inv: it is zero (:314)
-        for (int r = tid; r < R; r += nt) {
+        for (int r = tid; r < rows; r += nt) {
             double* s = S + r * mp; double* d = D + r * mp;
             if (!INV) d[m - 1] = (s[m - 2] * WR_EXT0 + d[m - 2] * WR_EXT1) + s[m - 1] * WR_EXT2;
             else d[m - 1] = 0.0;
         }
         __syncthreads();
     }
-    const int np = R * m;
+    // one lifting sweep over all staged lines: ODD updates d from s, else s from d; SGN = +1 / -1
+    auto sweep = [&](bool upd_d, double c, double sgn) {
+        for (int r = 0; r < rows; r++) {
+            double* s = S + r * mp; double* d = D + r * mp;
+            for (int i = tid; i < m; i += nt) {
+                if (upd_d) {
+                    const double t = (i < m - 1) ? c * (s[i + 1] + s[i]) : (c * 2) * s[i];
+                    d[i] = (sgn > 0) ? d[i] + t : d[i] - t;
+                } else {
+                    const double t = (i > 0) ? c * (d[i] + d[i - 1]) : (c * 2) * d[i];
+                    s[i] = (sgn > 0) ? s[i] + t : s[i] - t;
+                }
+            }
+        }
+        __syncthreads();
+    };
     if (!INV) {
-        for (int e = tid; e < np; e += nt) {  // d += alpha (s[i+1]+s[i])
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            d[i] = (i < m - 1) ? d[i] + WR_ALPHA * (s[i + 1] + s[i]) : d[i] + (WR_ALPHA * 2) * s[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < np; e += nt) {  // s += beta (d[i]+d[i-1])
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            s[i] = (i > 0) ? s[i] + WR_BETA * (d[i] + d[i - 1]) : s[i] + (WR_BETA * 2) * d[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < np; e += nt) {
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            d[i] = (i < m - 1) ? d[i] + WR_GAMMA * (s[i + 1] + s[i]) : d[i] + (WR_GAMMA * 2) * s[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < np; e += nt) {
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            s[i] = (i > 0) ? s[i] + WR_DELTA * (d[i] + d[i - 1]) : s[i] + (WR_DELTA * 2) * d[i];
-        }
+        sweep(true, WR_ALPHA, 1.0); sweep(false, WR_BETA, 1.0); sweep(true, WR_GAMMA, 1.0); sweep(false, WR_DELTA, 1.0);
     } else {
-        for (int e = tid; e < np; e += nt) {
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            s[i] = (i > 0) ? s[i] - WR_DELTA * (d[i] + d[i - 1]) : s[i] - (WR_DELTA * 2) * d[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < np; e += nt) {
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            d[i] = (i < m - 1) ? d[i] - WR_GAMMA * (s[i + 1] + s[i]) : d[i] - (WR_GAMMA * 2) * s[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < np; e += nt) {
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            s[i] = (i > 0) ? s[i] - WR_BETA * (d[i] + d[i - 1]) : s[i] - (WR_BETA * 2) * d[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < np; e += nt) {
-            int r = e / m, i = e - r * m; double* s = S + r * mp; double* d = D + r * mp;
-            d[i] = (i < m - 1) ? d[i] - WR_ALPHA * (s[i + 1] + s[i]) : d[i] - (WR_ALPHA * 2) * s[i];
-        }
+        sweep(false, WR_DELTA, -1.0); sweep(true, WR_GAMMA, -1.0); sweep(false, WR_BETA, -1.0); sweep(true, WR_ALPHA, -1.0);
     }
-    __syncthreads();
     // ---- store (coalesced): fwd = [low | high] with scaling, inv = interleave
-    for (int e = tid; e < R * n; e += nt) {
-        int r = e / n, j = e - r * n;
-        long long line = line0 + r;
-        if (line >= nlines) break;
-        size_t base = (size_t)(line % n2) * sy + (size_t)(line / n2) * sz;
-        double v;
-        if (!INV) v = (j < m) ? S[r * mp + j] * WR_ZETA : D[r * mp + (j - m)] * WR_IZETA;
-        else v = (j & 1) ? D[r * mp + (j >> 1)] : S[r * mp + (j >> 1)];
-        X[base + j] = v;
+    for (int r = 0; r < rows; r++) {
+        const long long line = line0 + r;
+        double* dst = X + (size_t)(line % n2) * sy + (size_t)(line / n2) * sz;
+        const double* s = S + r * mp; const double* d = D + r * mp;
+        for (int j = tid; j < n; j += nt) {
+            double v;
+            if (!INV) v = (j < m) ? s[j] * WR_ZETA : d[j - m] * WR_IZETA;
+            else v = (j & 1) ? d[j >> 1] : s[j >> 1];
+            dst[j] = v;
+        }
     }
 }
 
