@@ -574,7 +574,6 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 bool fused_ok(int nx, int ny, int nz, int lvl)
 {
     if (lvl != 4 && lvl != -4) return false;
-    if (lvl < 0 && nx % 32 != 0) return false;  // inverse: the x-high half must start 16-byte aligned at every level
     return nx % 16 == 0 && ny % 16 == 0 && nz % 16 == 0 && nx >= 64 && ny >= 64 && nz >= 64 &&
            (size_t)nx * ny < (1u << 30);
 }
@@ -654,12 +653,18 @@ void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx,
     double* cbuf[4] = {nullptr, lowbuf, nullptr, nullptr};
     cbuf[2] = cbuf[1] + (size_t)(nx >> 1) * (ny >> 1) * (nz >> 1);
     cbuf[3] = cbuf[2] + (size_t)(nx >> 2) * (ny >> 2) * (nz >> 2);
-    for (int l = 3; l >= 0; l--) {
+    // The fused inverse streams 16-byte chunks of the x-high half of every row, which starts at
+    // column m1 = n1/2: at level 3 that is nx/16, odd when nx % 32 == 16.  That one small level is
+    // then done by the general kernels, in place on the coefficient array (dst serves as their
+    // ping-pong scratch: nothing has been written to it yet).
+    const bool general_l3 = (nx >> 4) & 1;
+    if (general_l3) transform_level(const_cast<double*>(src), dst, nx, ny, nz, 3, true, st);
+    for (int l = general_l3 ? 2 : 3; l >= 0; l--) {
         const int n1 = nx >> l, n2 = ny >> l, n3 = nz >> l;
         const int m1 = n1 / 2, m2 = n2 / 2, m3 = n3 / 2;
         const double* lo;
         size_t lo_sy, lo_sz;
-        if (l == 3) { lo = src; lo_sy = f_sy; lo_sz = f_sz; }
+        if (l == 3 || (l == 2 && general_l3)) { lo = src; lo_sy = f_sy; lo_sz = f_sz; }
         else { lo = cbuf[l + 1]; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
         double* o;
         size_t o_sy, o_sz;

@@ -14,6 +14,8 @@ namespace wrk {
 // In place on `fld` (nx*ny*nz doubles, x fastest); `scratch` is a second buffer of the same
 // size.  lvl > 0 forward, lvl < 0 inverse, 0 identity.
 void transform(double* fld, double* scratch, int nx, int ny, int nz, int lvl, hipStream_t st);
+// one level of the above: the box ceil(n / 2^k), in place on `fld`
+void transform_level(double* fld, double* scratch, int nx, int ny, int nz, int k, bool inverse, hipStream_t st);
 
 // ---- reductions (reference src/core/wrappers.cpp:244-250, 308-314)
 // partial[] needs 2*minmax_partials() doubles; result (min, max) lands in result[0..1] (device).
@@ -68,7 +70,8 @@ void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st
 namespace wrk {
 // ---- fused single-pass-per-level transform (wr_fused.hip).  Usable when every level's box
 // is even in all three directions: nx, ny, nz multiples of 16 and >= 64 (fused_ok()).
-// Out of place: reads `src` (left untouched), writes all coefficients to `dst`; `lowbuf`
+// Out of place: reads `src` (the forward leaves it untouched; the inverse may rewrite the coarsest
+// corner box of its coefficient array in place), writes the result to `dst`; `lowbuf`
 // is work space for the compact low-pass boxes of levels 1..3 (fused_lowbuf_elems() doubles).
 bool fused_ok(int nx, int ny, int nz, int lvl);
 size_t fused_lowbuf_elems(int nx, int ny, int nz);

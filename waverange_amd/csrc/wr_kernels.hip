@@ -250,12 +250,17 @@ static void launch_stream(bool inv, const double* src, double* dst, int axis, in
 
 void transform(double* fld, double* scratch, int nx, int ny, int nz, int lvl, hipStream_t st)
 {
+    const int nl = lvl >= 0 ? lvl : -lvl;
+    // forward visits boxes ceil(n/1), ceil(n/2), ...; inverse visits them coarsest first
+    for (int step = 0; step < nl; step++) transform_level(fld, scratch, nx, ny, nz, lvl >= 0 ? step : nl - 1 - step, lvl < 0, st);
+}
+
+void transform_level(double* fld, double* scratch, int nx, int ny, int nz, int k, bool inverse, hipStream_t st)
+{
     const size_t sy = (size_t)nx, sz = (size_t)nx * (size_t)ny;
     auto up = [](int v, int p) { return v / p + (v % p ? 1 : 0); };
-    const int nl = lvl >= 0 ? lvl : -lvl;
-    for (int step = 0; step < nl; step++) {
-        // forward visits boxes ceil(n/1), ceil(n/2), ...; inverse visits them coarsest first
-        const int k = lvl >= 0 ? step : nl - 1 - step;
+    const int lvl = inverse ? -1 : 1;
+    {
         const int n1 = up(nx, 1 << k), n2 = up(ny, 1 << k), n3 = up(nz, 1 << k);
         double* cur = fld;
         double* oth = scratch;
