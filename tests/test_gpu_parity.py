@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(64, 64, 64), (13, 9, 7), (37, 21, 13), (33, 5, 1), (2, 2, 2), (3, 3, 3), (17, 1, 1),
           (9, 1, 40), (1, 4, 1), (100, 3, 2), (130, 70, 34), (256, 8, 4), (1030, 6, 5), (257, 129, 65),
           # multiples of 16 and >= 64: the fused single-pass-per-level kernels
-          (128, 64, 80), (96, 64, 64), (64, 128, 64), (272, 96, 64), (64, 64, 144)]
+          (128, 64, 80), (96, 64, 64), (64, 128, 64), (272, 96, 64), (64, 64, 144),
+          # even at the finest levels only: fused levels on top, general kernels for the coarse rest
+          (200, 120, 72), (136, 88, 40), (260, 132, 68), (72, 200, 104)]
 
 
 @pytest.fixture(scope="module")
@@ -167,7 +169,8 @@ def test_codec_golden_64(ctx, golden, tol):
 
 @pytest.mark.parametrize("shape,tol,wtflag", [((37, 21, 13), 1e-6, 1), ((64, 64, 8), 1e-4, 0),
                                               ((60, 50, 40), 1e-10, 1), ((5, 1, 33), 1e-3, 1),
-                                              ((128, 128, 128), 1e-5, 1), ((2, 1, 1), 1e-3, 1)])
+                                              ((128, 128, 128), 1e-5, 1), ((2, 1, 1), 1e-3, 1),
+                                              ((200, 120, 72), 1e-6, 1), ((260, 132, 68), 1e-4, 1)])
 def test_codec_vs_oracle(ctx, oracle, shape, tol, wtflag):
     nx, ny, nz = shape
     f = synth.field(nx, ny, nz, seed=4242)

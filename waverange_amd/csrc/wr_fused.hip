@@ -571,11 +571,29 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 #endif
 }
 
+// Number of leading levels (finest first) the fused kernels can take; the remaining, coarser
+// levels run on the general kernels.  A level is fusable when its box is even in every direction
+// (no odd-length synthesis in the fused kernels), at least 8 long, and -- inverse only -- when the
+// x-high half of a row starts 16-byte aligned (n1 % 4 == 0: its rows are fetched in 16-byte chunks).
+int fused_levels(int nx, int ny, int nz, bool inverse)
+{
+    if ((size_t)nx * ny >= (1u << 30)) return 0;  // per-plane offsets are 32-bit
+    int l = 0;
+    for (; l < 4; l++) {
+        const int n1 = nx >> l, n2 = ny >> l, n3 = nz >> l;
+        if ((n1 | n2 | n3) & 1) break;
+        if (n1 < 8 || n2 < 8 || n3 < 8) break;
+        if (inverse && (n1 & 3)) break;
+    }
+    return l;
+}
+
 bool fused_ok(int nx, int ny, int nz, int lvl)
 {
     if (lvl != 4 && lvl != -4) return false;
-    return nx % 16 == 0 && ny % 16 == 0 && nz % 16 == 0 && nx >= 64 && ny >= 64 && nz >= 64 &&
-           (size_t)nx * ny < (1u << 30);
+    // worth it from two fused levels on (98 % of the bytes), or one level of a big field
+    const int f = fused_levels(nx, ny, nz, lvl < 0);
+    return f >= 2 || (f == 1 && (size_t)nx * ny * nz >= (1u << 21));
 }
 
 size_t fused_lowbuf_elems(int nx, int ny, int nz)
@@ -614,20 +632,22 @@ extern "C" unsigned long long* wr_stamp_buffer(size_t nwaves)
 }
 #endif
 
-void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
+void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES); });
     const size_t d_sy = (size_t)nx, d_sz = (size_t)nx * ny;
+    const int nfused = fused_levels(nx, ny, nz, false);
     const double* in = src;
     size_t in_sy = d_sy, in_sz = d_sz;
     double* lb = lowbuf;
-    for (int l = 0; l < 4; l++) {
+    for (int l = 0; l < nfused; l++) {
         const int n1 = nx >> l, n2 = ny >> l, n3 = nz >> l;
         const int m1 = n1 / 2, m2 = n2 / 2, m3 = n3 / 2;
         double* lo;
         size_t lo_sy, lo_sz;
-        if (l < 3) { lo = lb; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
+        // the last fused level leaves its low-pass octant in the coefficient array itself
+        if (l < nfused - 1) { lo = lb; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
         else { lo = dst; lo_sy = d_sy; lo_sz = d_sz; }
         const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
         const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_BYTES));
@@ -642,29 +662,32 @@ void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx,
         in = lo; in_sy = lo_sy; in_sz = lo_sz;
         lb += (size_t)m1 * m2 * m3;
     }
+    // coarser levels whose boxes are odd somewhere: general kernels, in place on the corner box of
+    // dst; the input array has been fully consumed by level 0 and serves as their ping-pong scratch
+    for (int k = nfused; k < 4; k++) transform_level(dst, src, nx, ny, nz, k, false, st);
 }
 
-void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
+void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
     static std::once_flag once;
     std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_inv_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV); });
     const size_t f_sy = (size_t)nx, f_sz = (size_t)nx * ny;
+    const int nfused = fused_levels(nx, ny, nz, true);
     // compact reconstruction buffers: C1 = (n/2)^3, C2 = (n/4)^3, C3 = (n/8)^3, laid out as in the forward pass
     double* cbuf[4] = {nullptr, lowbuf, nullptr, nullptr};
     cbuf[2] = cbuf[1] + (size_t)(nx >> 1) * (ny >> 1) * (nz >> 1);
     cbuf[3] = cbuf[2] + (size_t)(nx >> 2) * (ny >> 2) * (nz >> 2);
-    // The fused inverse streams 16-byte chunks of the x-high half of every row, which starts at
-    // column m1 = n1/2: at level 3 that is nx/16, odd when nx % 32 == 16.  That one small level is
-    // then done by the general kernels, in place on the coefficient array (dst serves as their
-    // ping-pong scratch: nothing has been written to it yet).
-    const bool general_l3 = (nx >> 4) & 1;
-    if (general_l3) transform_level(const_cast<double*>(src), dst, nx, ny, nz, 3, true, st);
-    for (int l = general_l3 ? 2 : 3; l >= 0; l--) {
+    // coarsest levels the fused kernel cannot take (odd boxes, or an x-high half that is not 16-byte
+    // aligned): general kernels, in place on the corner box of the coefficient array; dst has not
+    // been written yet and serves as their ping-pong scratch
+    for (int k = 3; k >= nfused; k--) transform_level(src, dst, nx, ny, nz, k, true, st);
+    for (int l = nfused - 1; l >= 0; l--) {
         const int n1 = nx >> l, n2 = ny >> l, n3 = nz >> l;
         const int m1 = n1 / 2, m2 = n2 / 2, m3 = n3 / 2;
         const double* lo;
         size_t lo_sy, lo_sz;
-        if (l == 3 || (l == 2 && general_l3)) { lo = src; lo_sy = f_sy; lo_sz = f_sz; }
+        // the coarsest fused level finds its low-pass octant in the coefficient array itself
+        if (l == nfused - 1) { lo = src; lo_sy = f_sy; lo_sz = f_sz; }
         else { lo = cbuf[l + 1]; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
         double* o;
         size_t o_sy, o_sz;

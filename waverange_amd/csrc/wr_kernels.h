@@ -68,13 +68,16 @@ void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st
 }  // namespace wrk
 
 namespace wrk {
-// ---- fused single-pass-per-level transform (wr_fused.hip).  Usable when every level's box
-// is even in all three directions: nx, ny, nz multiples of 16 and >= 64 (fused_ok()).
-// Out of place: reads `src` (the forward leaves it untouched; the inverse may rewrite the coarsest
-// corner box of its coefficient array in place), writes the result to `dst`; `lowbuf`
-// is work space for the compact low-pass boxes of levels 1..3 (fused_lowbuf_elems() doubles).
+// ---- fused single-pass-per-level transform (wr_fused.hip).  The finest levels whose boxes are even
+// in all three directions (and, for the inverse, whose x extent is a multiple of 4) run fused, the
+// remaining coarser levels on the general kernels: fused_levels().  A 1024^3 field runs all four
+// levels fused, 1000^3 three forward / two inverse, 500^3 two / one.
+// Out of place: the result lands in `dst`; `src` is CONSUMED (the general levels use the forward's
+// input array as scratch, the inverse rewrites the coarse corner of its coefficient array);
+// `lowbuf` holds the compact low-pass boxes between fused levels (fused_lowbuf_elems() doubles).
+int fused_levels(int nx, int ny, int nz, bool inverse);
 bool fused_ok(int nx, int ny, int nz, int lvl);
 size_t fused_lowbuf_elems(int nx, int ny, int nz);
-void transform_fwd_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
-void transform_inv_fused(const double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
+void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
+void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
 }  // namespace wrk
