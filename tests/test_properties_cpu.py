@@ -1,0 +1,44 @@
+"""Property-based checks (hypothesis) on the CPU side: product range coder == oracle range coder on
+arbitrary planes, stream anchors, transform round trips of the oracle on arbitrary small shapes."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from oracle.loader import Oracle
+from waverange_amd import api
+
+_o = Oracle()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 70000), st.integers(0, 2 ** 31 - 1), st.sampled_from(["uniform", "two", "skew", "runs"]))
+def test_range_coder_matches_oracle(n, seed, kind):
+    rs = np.random.RandomState(seed)
+    if kind == "uniform":
+        p = rs.randint(0, 256, n)
+    elif kind == "two":
+        p = rs.choice([3, 250], size=n, p=[0.97, 0.03])
+    elif kind == "skew":
+        p = np.minimum(rs.geometric(rs.uniform(0.02, 0.9), n), 255)
+    else:
+        p = np.repeat(rs.randint(0, 256, n // 50 + 1), 50)[:n]
+    p = p.astype(np.uint8)
+    s = api.range_encode(p)
+    assert np.array_equal(s, _o.range_encode(p))
+    assert s[0] == 0 and (int(s[-3]) << 16 | int(s[-2]) << 8 | int(s[-1])) == s.size % (1 << 24)
+    back, got = api.range_decode(s, n)
+    assert got == n and np.array_equal(back, p)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 40), st.integers(1, 24), st.integers(1, 20), st.integers(0, 1000))
+def test_oracle_transform_round_trip(nx, ny, nz, seed):
+    rs = np.random.RandomState(seed)
+    f = rs.standard_normal((nz, ny, nx))
+    w = _o.cdf97_3d(f, 4)
+    r = _o.cdf97_3d(w, -4)
+    assert np.abs(r - f).max() <= 1e-12 * max(1.0, np.abs(f).max())
+    # linearity of the transform (it is a linear map; round-off level agreement)
+    g = rs.standard_normal((nz, ny, nx))
+    lhs = _o.cdf97_3d(f + 2.0 * g, 4)
+    rhs = w + 2.0 * _o.cdf97_3d(g, 4)
+    assert np.abs(lhs - rhs).max() <= 1e-11 * max(1.0, np.abs(lhs).max())
