@@ -95,3 +95,20 @@ def test_sharded_driver_with_gpu_codec(golden_cli):
                                   specs, c["file_type"], bool(c["flip"]), codec)
             assert open(os.path.join(d, "data.wrh")).read() == golden_cli[case]["wrh"]
             assert sha_file(os.path.join(d, "data.wrb")) == golden_cli[case]["wrb_sha256"]
+
+
+@pytest.mark.gpu
+def test_c_example_links_against_library_under_reference_name():
+    """examples/example_roundtrip.c: a plain C client, linked with -lwaverange (the reference's
+    library name), runs on the GPU and meets the tolerance."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = os.path.join(ROOT, "waverange_amd")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "example_roundtrip")
+        subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "example_roundtrip.c"),
+                               "-o", exe, "-L" + lib, "-lwaverange", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+        r = subprocess.run([exe, "1e-6"], capture_output=True, text=True, env=dict(os.environ, WR_QUIET="1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Linf_rel" in r.stdout
