@@ -5,6 +5,8 @@ import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from waverange_amd import api
+if os.environ.get('WR_AB_LIB'):  # A/B runs of an experimental build of the library
+    api.LIB_PATH = os.path.abspath(os.environ['WR_AB_LIB'])
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -329,7 +329,7 @@ constexpr int HY = ITYP + 4;              // coefficient rows per quadrant (20)
 constexpr int CROW = HX / 2;             // 16-byte chunks per row (34)
 constexpr int NCI = 4 * HY * CROW;       // chunks per plane (2720)
 constexpr int KCI = (NCI + INTHR - 1) / INTHR;  // chunk slots per thread (6)
-constexpr size_t LDS_INV = (size_t)3 * NCI * 16 + (size_t)INWAVE * 2 * (2 * HX) * 8;
+constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * 2 * (2 * HX) * 8;
 
 // whole-sample symmetric extension in coefficient space (even length 2M):
 //   low-pass  s[-k] = s[k],    s[M-1+k] = s[M-k]
@@ -373,9 +373,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ double2 lds2[];
-    double2* in = lds2;                   // [2][NCI]   staged low-z / high-z coefficient planes
-    double2* zb = lds2 + 2 * NCI;         // [NCI]      one z-reconstructed plane
-    double* yb = reinterpret_cast<double*>(lds2 + 3 * NCI);  // [INWAVE][2][2*HX] wave-private rows
+    double2* zb = lds2;                   // [2][NCI]   the two z-reconstructed planes of a step
+    double* yb = reinterpret_cast<double*>(lds2 + 2 * NCI);  // [INWAVE][2][2*HX] wave-private rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + TXP - 1) / TXP;
@@ -402,21 +401,18 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         offL[k] = (q == 0) ? (int)(gyp * l_sy) + gxp : so;
         if (q == 0) lll_mask |= 1u << k;
     }
-    // chunk slots [k0, k1) of z-pair t; issued in three bursts spread over the step, because
-    // 96 global_load_lds per CU in one burst stall in the issue queue (profiles/r01/NOTES.md)
-    auto fetch = [&](int t, int k0, int k1) {
-        const double* pl = src + (size_t)t * s_sz;         // low-z plane, detail quadrants
-        const double* pll = low + (size_t)t * l_sz;        // low-z plane, LL quadrant
-        const double* ph = src + (size_t)(m3 + t) * s_sz;  // high-z plane
+    // the coefficient chunks of z-pair t go straight into registers: the z step is the only reader,
+    // it runs first in a step, and the registers are free again for the next pair right after it
+    double2 rl[KCI], rh[KCI];
+    auto fetch = [&](int t, int, int) {
+        const double* pl = src + (size_t)t * s_sz;
+        const double* pll = low + (size_t)t * l_sz;
+        const double* ph = src + (size_t)(m3 + t) * s_sz;
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
-            if (k >= k0 && k < k1 && tid + INTHR * k < NCI) {
-                double2* l0 = in + INTHR * k + (w << 6);
-                const double* gl = ((lll_mask >> k) & 1) ? pll + offL[k] : pl + offL[k];
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gl,
-                                                 (__attribute__((address_space(3))) void*)l0, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ph + offH[k]),
-                                                 (__attribute__((address_space(3))) void*)(l0 + NCI), 16, 0, 0);
+            if (tid + INTHR * k < NCI) {
+                rl[k] = *reinterpret_cast<const double2*>((((lll_mask >> k) & 1) ? pll : pl) + offL[k]);
+                rh[k] = *reinterpret_cast<const double2*>(ph + offH[k]);
             }
         }
     };
@@ -457,7 +453,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         }
     };
     // y + x stages of the z-plane held in zb
-    auto yxstage = [&](int zplane) {
+    auto yxstage = [&](int zplane, const double2* zbuf) {
         double keep[3][2];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -465,8 +461,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
             if (cid < 2 * HX) {
                 const int xh = cid >= HX;             // 0: x-low column, 1: x-high column
                 const int col = cid - xh * HX;
-                const double* zl = reinterpret_cast<const double*>(zb) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
-                const double* zh = reinterpret_cast<const double*>(zb) + (size_t)(2 + xh) * (HY * HX) + col;    // y-high quadrant
+                const double* zl = reinterpret_cast<const double*>(zbuf) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
+                const double* zh = reinterpret_cast<const double*>(zbuf) + (size_t)(2 + xh) * (HY * HX) + col;    // y-high quadrant
                 // local row of y-pair k is k + 2:  s[J-1..J+3] -> rows J+1..J+5,  d[J-2..J+3] -> rows J..J+5
                 const double sr[5] = {zl[(J + 1) * HX], zl[(J + 2) * HX], zl[(J + 3) * HX], zl[(J + 4) * HX], zl[(J + 5) * HX]};
                 const double dr[6] = {zh[(J + 0) * HX], zh[(J + 1) * HX], zh[(J + 2) * HX], zh[(J + 3) * HX], zh[(J + 4) * HX],
@@ -499,11 +495,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     for (int t = tb; t <= te; t++) {
         const int j = t - 2;
         const bool emit = j >= z0 && j < z1;  // block-uniform
-        double2 odd[KCI];
         STAMP(7);
-        if (t < m3) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's chunks have landed
-        STAMP(0);
-        __syncthreads();  // everybody's chunks have landed; the previous step's readers of zb are done
+        lds_barrier();  // the previous step's readers of zb are done
         STAMP(1);
         // ---- z step on every staged point  (waveletcdf97_3d.c:312-337 along z)
 #pragma unroll
@@ -511,10 +504,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
             const int c = tid + INTHR * k;
             if (c < NCI) {
                 double lo[2] = {0, 0}, hi[2] = {0, 0};
-                if (t < m3) {
-                    const double2 vl = in[c], vh = in[NCI + c];
-                    lo[0] = vl.x; lo[1] = vl.y; hi[0] = vh.x; hi[1] = vh.y;
-                }
+                if (t < m3) { lo[0] = rl[k].x; lo[1] = rl[k].y; hi[0] = rh[k].x; hi[1] = rh[k].y; }
                 double ev[2], od[2];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
@@ -535,33 +525,17 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                                          : d1prev[k][e] - (WR_ALPHA * 2) * s2prev[k][e];
                     dprev[k][e] = d0; s1prev[k][e] = S1; d1prev[k][e] = D1; s2prev[k][e] = S2;
                 }
-                if (emit) zb[c] = make_double2(ev[0], ev[1]);
-                odd[k] = make_double2(od[0], od[1]);
+                if (emit) { zb[c] = make_double2(ev[0], ev[1]); zb[NCI + c] = make_double2(od[0], od[1]); }
             }
         }
         STAMP(2);
-        lds_barrier();  // zb complete; `in` fully consumed
-        STAMP(6);
-        const bool more = t + 1 <= te && t + 1 < m3;
-        constexpr int K1 = (KCI + 2) / 3, K2 = (2 * KCI + 2) / 3;
-        if (more) fetch(t + 1, 0, emit ? K1 : KCI);  // streams in behind the y/x stages
+        if (t + 1 <= te && t + 1 < m3) fetch(t + 1, 0, KCI);  // in flight behind the y/x stages
         STAMP(3);
+        lds_barrier();  // both planes complete
+        STAMP(6);
         if (emit) {
-            yxstage(2 * j);
-            STAMP(4);
-            lds_barrier();
-            STAMP(6);
-            if (more) fetch(t + 1, K1, K2);
-            STAMP(3);
-#pragma unroll
-            for (int k = 0; k < KCI; k++)
-                if (tid + INTHR * k < NCI) zb[tid + INTHR * k] = odd[k];
-            STAMP(5);
-            lds_barrier();
-            STAMP(6);
-            if (more) fetch(t + 1, K2, KCI);
-            STAMP(3);
-            yxstage(2 * j + 1);
+            yxstage(2 * j, zb);
+            yxstage(2 * j + 1, zb + NCI);
             STAMP(4);
         }
     }
