@@ -199,6 +199,14 @@ int wr_decode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz,
 size_t wr_range_encode_bound(size_t n);
 size_t wr_range_encode(const unsigned char *sym, size_t n, unsigned char *out);
 size_t wr_range_decode(const unsigned char *in, size_t len, unsigned char *sym, size_t n);
+/* `count` planes of n symbols each coded on the calling thread, their symbol loops interleaved
+ * (up to 4 at a time): the same bytes as `count` calls of the functions above, at a fraction of
+ * the CPU time, because one plane's coder is a serial dependency chain that leaves most of a
+ * core idle.  out[k] holds wr_range_encode_bound(n) bytes; produced[k] as wr_range_decode. */
+void wr_range_encode_multi(int count, const unsigned char *const *sym, size_t n,
+                           unsigned char *const *out, size_t *lens);
+void wr_range_decode_multi(int count, const unsigned char *const *in, const size_t *len,
+                           unsigned char *const *sym, size_t n, size_t *produced);
 
 /* --- measurement hook for bench.py: runs `reps` forward (lvl>0) or inverse transforms of an
  * nx*ny*nz field back to back on the context's stream and returns the average duration of

@@ -29,6 +29,40 @@ int main() {
             (void)wrrc::decode_plane(bad.data(), bad.size(), dst.data(), n);
         }
     }
+    // several planes interleaved in one loop (encode_planes / decode_planes): same bytes as one by one,
+    // streams long enough for the unchecked fast loop (needs 3 * 60000 + 8 unread bytes per stream)
+    for (size_t n : {(size_t)7, (size_t)60000 * 2, (size_t)60000 * 9 + 17}) for (int count = 1; count <= 6; count++) {
+        std::vector<std::vector<uint8_t>> p(count), one(count), multi(count), back(count);
+        std::vector<const uint8_t*> pp(count), ip(count);
+        std::vector<uint8_t*> op(count), bp(count);
+        std::vector<size_t> len1(count), lenm(count), got(count);
+        for (int k = 0; k < count; k++) {
+            p[k].resize(n); one[k].resize(wrrc::encode_bound(n)); multi[k].resize(wrrc::encode_bound(n)); back[k].resize(n);
+            for (size_t i = 0; i < n; i++) { unsigned r = rnd(); p[k][i] = k % 3 == 0 ? r & 255 : k % 3 == 1 ? (r & 255) % 23 + 100 : ((r & 63) ? 128 : r >> 8 & 255); }
+            len1[k] = wrrc::encode_plane(p[k].data(), n, one[k].data(), nullptr);
+            pp[k] = p[k].data(); op[k] = multi[k].data();
+        }
+        wrrc::encode_planes(count, pp.data(), n, op.data(), nullptr, lenm.data());
+        for (int k = 0; k < count; k++) {
+            if (lenm[k] != len1[k] || memcmp(multi[k].data(), one[k].data(), len1[k])) { printf("interleaved encode differs n=%zu count=%d k=%d\n", n, count, k); return 1; }
+            multi[k].resize(len1[k]); multi[k].shrink_to_fit();  // exact size: over-reads are caught
+            ip[k] = multi[k].data(); bp[k] = back[k].data();
+        }
+        wrrc::decode_planes(count, ip.data(), len1.data(), bp.data(), n, got.data());
+        for (int k = 0; k < count; k++)
+            if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("interleaved decode failed n=%zu count=%d k=%d\n", n, count, k); return 1; }
+        for (int trial = 0; trial < 4; trial++) {  // one damaged stream among healthy ones
+            const int victim = (int)(rnd() % count);
+            std::vector<uint8_t> bad(multi[victim]);
+            if (trial < 2) bad.resize(bad.size() * (trial + 1) / 3);
+            else for (int j = 0; j < 16; j++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
+            std::vector<const uint8_t*> ip2(ip); std::vector<size_t> l2(len1);
+            ip2[victim] = bad.data(); l2[victim] = bad.size();
+            wrrc::decode_planes(count, ip2.data(), l2.data(), bp.data(), n, got.data());
+            for (int k = 0; k < count; k++)
+                if (k != victim && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("healthy stream disturbed by a damaged one\n"); return 1; }
+        }
+    }
     printf("range coder sanitizer run OK\n");
     return 0;
 }

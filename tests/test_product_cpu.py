@@ -78,6 +78,29 @@ def test_range_coder_vs_oracle_random(api, oracle):
             assert og == n and np.array_equal(ob, p)
 
 
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 7])
+def test_interleaved_planes_same_bytes_as_oracle(api, oracle, count):
+    """wr_range_encode_multi / wr_range_decode_multi (several planes in one symbol loop) against the
+    oracle's coder plane by plane; the planes are shaped like real bit planes (one dominant symbol, two
+    symbols, noise) so that the decoder's division-free shortcut, its bucket table and its padded-tail
+    path all run.  n is not a multiple of the block size and > 3 blocks of margin."""
+    n = 60000 * 7 + 4321
+    rs = np.random.RandomState(count)
+    u = rs.random_sample(n)
+    shapes = [np.where(u < 0.9997, 121, rs.randint(0, 256, n)),
+              np.where(u < 0.737, 189, np.where(u < 0.994, 190, rs.randint(0, 256, n))),
+              rs.randint(0, 256, n), np.where(u < 0.5, 255, 254),  # 255 = largest symbol is also the most probable
+              np.clip(np.rint(rs.normal(128, 12, n)), 0, 255), rs.randint(0, 4, n), np.full(n, 7)]
+    planes = [shapes[i % len(shapes)].astype(np.uint8) for i in range(count)]
+    streams = api.range_encode_multi(planes)
+    for p, s in zip(planes, streams):
+        assert np.array_equal(s, oracle.range_encode(p))
+    back, got = api.range_decode_multi(streams, n)
+    assert got == [n] * count
+    for p, b in zip(planes, back):
+        assert np.array_equal(p, b)
+
+
 def test_range_decoder_rejects_garbage(api):
     rs = np.random.RandomState(5)
     junk = rs.randint(0, 256, 4096).astype(np.uint8)

@@ -108,6 +108,10 @@ def lib():
     L.wr_range_encode.argtypes = [_vp, C.c_size_t, _vp]
     L.wr_range_decode.restype = C.c_size_t
     L.wr_range_decode.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t]
+    L.wr_range_encode_multi.restype = None
+    L.wr_range_encode_multi.argtypes = [C.c_int, _vp, C.c_size_t, _vp, _vp]
+    L.wr_range_decode_multi.restype = None
+    L.wr_range_decode_multi.argtypes = [C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]
     L.wr_bench_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     # drop-in symbols (reference src/core/wrappers.h:53,70,75)
     L.setup_wr.argtypes = [C.c_int] * 3 + [_u8p, _ulp]
@@ -151,6 +155,28 @@ def range_decode(stream, n):
     out = np.zeros(max(n, 1), dtype=np.uint8)
     got = lib().wr_range_decode(s.ctypes.data, s.size, out.ctypes.data, n)
     return out[:n], got
+
+
+def range_encode_multi(planes):
+    """Code several equally long planes on this thread with interleaved symbol loops (wr_range_encode_multi)."""
+    ps = [np.ascontiguousarray(p, dtype=np.uint8).ravel() for p in planes]
+    n, k = ps[0].size, len(ps)
+    assert all(p.size == n for p in ps)
+    outs = [np.empty(lib().wr_range_encode_bound(n), dtype=np.uint8) for _ in ps]
+    lens = (C.c_size_t * k)()
+    lib().wr_range_encode_multi(k, (C.c_void_p * k)(*[p.ctypes.data for p in ps]), n,
+                                (C.c_void_p * k)(*[o.ctypes.data for o in outs]), lens)
+    return [o[:lens[i]].copy() for i, o in enumerate(outs)]
+
+
+def range_decode_multi(streams, n):
+    ss = [np.ascontiguousarray(s, dtype=np.uint8).ravel() for s in streams]
+    k = len(ss)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for _ in ss]
+    got = (C.c_size_t * k)()
+    lib().wr_range_decode_multi(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
+                                (C.c_void_p * k)(*[o.ctypes.data for o in outs]), n, got)
+    return [o[:n] for o in outs], [got[i] for i in range(k)]
 
 
 # ---------------------------------------------------------------------------------------

@@ -38,7 +38,6 @@ constexpr unsigned long kSafetyBufferFactor = 1;
 thread_local std::string g_err;
 // Device phases of different contexts are serialised (they are tens of milliseconds); what
 // overlaps between concurrent encode/decode calls is the host range coding and the copies.
-std::mutex g_gpu_phase;
 int g_verbose = -1;  // -1: not initialised from the environment yet
 int g_threads = WR_NLAYMAX;
 
@@ -71,23 +70,34 @@ double now()
 
 }  // namespace
 
+// Device work space of the transform / quantizer phase, one per GPU and shared by all contexts on
+// it: a device phase holds `phase` from its first kernel to its last copy (phases of different
+// contexts would only fight over HBM bandwidth), so nothing in here is live outside the lock and
+// 1024^3 jobs cost 2 x 8.6 GB of HBM each (field in, field out) instead of 5 x.
+struct DevPool {
+    std::mutex phase;
+    int users = 0;
+    double* scratch = nullptr; size_t scratch_elems = 0;  // coefficient array (out-of-place fused transform)
+    uint8_t* planes = nullptr; size_t planes_bytes = 0;   // quantized planes
+    double* lowbuf = nullptr; size_t lowbuf_elems = 0;    // compact low-pass boxes (fused transform)
+    uint16_t* hist = nullptr; size_t hist_elems = 0;      // per-block byte histograms, all planes
+};
+
 struct wr_ctx {
     int device = 0;
+    DevPool* pool = nullptr;
     hipStream_t stream = nullptr, copy = nullptr;
     bool own_stream = false;
     bool keep_residual = false;
-    // device work space
-    double* d_scratch = nullptr; size_t scratch_elems = 0;
-    uint8_t* d_planes = nullptr; size_t planes_bytes = 0;
     double* d_field = nullptr; size_t field_elems = 0;  // staging for the host-pointer API
-    double* d_lowbuf = nullptr; size_t lowbuf_elems = 0;  // compact low-pass boxes (fused transform)
     double* d_cutoff = nullptr; size_t cutoff_elems = 0;  // local cutoff vector (mx*my*mz > 1 only)
     double* d_partial = nullptr; double* d_result = nullptr;
     unsigned long long* d_idx = nullptr;
     // pinned host
     double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index
     uint8_t* h_plane[WR_NLAYMAX] = {nullptr}; size_t h_plane_bytes[WR_NLAYMAX] = {0};  // pinned, one per plane, on demand
-    uint16_t* d_hist = nullptr; uint16_t* h_hist = nullptr; size_t hist_elems = 0;  // per-block byte histograms, all planes
+    bool h_plane_pinned[WR_NLAYMAX] = {false};
+    uint16_t* h_hist = nullptr; size_t h_hist_elems = 0;  // pinned: per-block byte histograms, all planes
     // host coded-stream staging, one per plane
     uint8_t* enc_buf[WR_NLAYMAX] = {nullptr}; size_t enc_buf_bytes[WR_NLAYMAX] = {0};  // malloc'd: only coded bytes get touched
     hipEvent_t ev_plane[WR_NLAYMAX], ev_copy[WR_NLAYMAX], ev_a, ev_b, ev_c, ev_d;
@@ -98,23 +108,32 @@ namespace {
 
 int ctx_bind(wr_ctx* c) { HIPCHK(hipSetDevice(c->device)); return WR_OK; }
 
+constexpr int kMaxDevices = 64;
+DevPool g_pools[kMaxDevices];
+std::mutex g_pools_mu;
+
+using PhaseLock = std::unique_lock<std::mutex>;
+
+// pool buffers: call with pool->phase held
 int ensure_scratch(wr_ctx* c, size_t n)
 {
-    if (c->scratch_elems >= n) return WR_OK;
-    if (c->d_scratch) HIPCHK(hipFree(c->d_scratch));
-    c->d_scratch = nullptr; c->scratch_elems = 0;
-    HIPCHK(hipMalloc(&c->d_scratch, n * sizeof(double)));
-    c->scratch_elems = n;
+    DevPool* p = c->pool;
+    if (p->scratch_elems >= n) return WR_OK;
+    if (p->scratch) HIPCHK(hipFree(p->scratch));
+    p->scratch = nullptr; p->scratch_elems = 0;
+    HIPCHK(hipMalloc(&p->scratch, n * sizeof(double)));
+    p->scratch_elems = n;
     return WR_OK;
 }
 
 int ensure_planes(wr_ctx* c, size_t bytes)
 {
-    if (c->planes_bytes >= bytes) return WR_OK;
-    if (c->d_planes) HIPCHK(hipFree(c->d_planes));
-    c->d_planes = nullptr; c->planes_bytes = 0;
-    HIPCHK(hipMalloc(&c->d_planes, bytes));
-    c->planes_bytes = bytes;
+    DevPool* p = c->pool;
+    if (p->planes_bytes >= bytes) return WR_OK;
+    if (p->planes) HIPCHK(hipFree(p->planes));
+    p->planes = nullptr; p->planes_bytes = 0;
+    HIPCHK(hipMalloc(&p->planes, bytes));
+    p->planes_bytes = bytes;
     return WR_OK;
 }
 
@@ -123,9 +142,18 @@ int ensure_planes(wr_ctx* c, size_t bytes)
 int ensure_host_plane(wr_ctx* c, int l, size_t bytes)
 {
     if (c->h_plane_bytes[l] >= bytes) return WR_OK;
-    if (c->h_plane[l]) HIPCHK(hipHostFree(c->h_plane[l]));
+    if (c->h_plane[l]) { if (c->h_plane_pinned[l]) HIPCHK(hipHostFree(c->h_plane[l])); else free(c->h_plane[l]); }
     c->h_plane[l] = nullptr; c->h_plane_bytes[l] = 0;
-    HIPCHK(hipHostMalloc(&c->h_plane[l], bytes, hipHostMallocDefault));
+    if (hipHostMalloc(&c->h_plane[l], bytes, hipHostMallocDefault) == hipSuccess) {
+        c->h_plane_pinned[l] = true;
+    } else {
+        // no pinned memory left (many contexts of many ranks on one host): pageable staging works,
+        // the copy is then staged by the runtime and slower
+        (void)hipGetLastError();
+        c->h_plane[l] = static_cast<uint8_t*>(aligned_alloc(4096, (bytes + 4095) / 4096 * 4096));
+        c->h_plane_pinned[l] = false;
+        if (!c->h_plane[l]) return fail(WR_ERR_ARG, "out of host memory for the plane staging buffer");
+    }
     c->h_plane_bytes[l] = bytes;
     return WR_OK;
 }
@@ -141,23 +169,30 @@ int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
 
 int ensure_hist(wr_ctx* c, size_t elems)
 {
-    if (c->hist_elems >= elems) return WR_OK;
-    if (c->d_hist) HIPCHK(hipFree(c->d_hist));
-    if (c->h_hist) HIPCHK(hipHostFree(c->h_hist));
-    c->d_hist = nullptr; c->h_hist = nullptr; c->hist_elems = 0;
-    HIPCHK(hipMalloc(&c->d_hist, elems * sizeof(uint16_t)));
-    HIPCHK(hipHostMalloc(&c->h_hist, elems * sizeof(uint16_t), hipHostMallocDefault));
-    c->hist_elems = elems;
+    DevPool* p = c->pool;
+    if (p->hist_elems < elems) {
+        if (p->hist) HIPCHK(hipFree(p->hist));
+        p->hist = nullptr; p->hist_elems = 0;
+        HIPCHK(hipMalloc(&p->hist, elems * sizeof(uint16_t)));
+        p->hist_elems = elems;
+    }
+    if (c->h_hist_elems < elems) {
+        if (c->h_hist) HIPCHK(hipHostFree(c->h_hist));
+        c->h_hist = nullptr; c->h_hist_elems = 0;
+        HIPCHK(hipHostMalloc(&c->h_hist, elems * sizeof(uint16_t), hipHostMallocDefault));
+        c->h_hist_elems = elems;
+    }
     return WR_OK;
 }
 
 int ensure_lowbuf(wr_ctx* c, size_t n)
 {
-    if (c->lowbuf_elems >= n) return WR_OK;
-    if (c->d_lowbuf) HIPCHK(hipFree(c->d_lowbuf));
-    c->d_lowbuf = nullptr; c->lowbuf_elems = 0;
-    HIPCHK(hipMalloc(&c->d_lowbuf, n * sizeof(double)));
-    c->lowbuf_elems = n;
+    DevPool* p = c->pool;
+    if (p->lowbuf_elems >= n) return WR_OK;
+    if (p->lowbuf) HIPCHK(hipFree(p->lowbuf));
+    p->lowbuf = nullptr; p->lowbuf_elems = 0;
+    HIPCHK(hipMalloc(&p->lowbuf, n * sizeof(double)));
+    p->lowbuf_elems = n;
     return WR_OK;
 }
 
@@ -170,11 +205,11 @@ int forward_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl,
     *coef = d_fld;
     if (wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED")) {
         if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
-        if (lvl > 0) wrk::transform_fwd_fused(d_fld, c->d_scratch, c->d_lowbuf, nx, ny, nz, c->stream);
-        else wrk::transform_inv_fused(d_fld, c->d_scratch, c->d_lowbuf, nx, ny, nz, c->stream);
-        *coef = c->d_scratch;
+        if (lvl > 0) wrk::transform_fwd_fused(d_fld, c->pool->scratch, c->pool->lowbuf, nx, ny, nz, c->stream);
+        else wrk::transform_inv_fused(d_fld, c->pool->scratch, c->pool->lowbuf, nx, ny, nz, c->stream);
+        *coef = c->pool->scratch;
     } else {
-        wrk::transform(d_fld, c->d_scratch, nx, ny, nz, lvl, c->stream);
+        wrk::transform(d_fld, c->pool->scratch, nx, ny, nz, lvl, c->stream);
     }
     return WR_OK;
 }
@@ -190,10 +225,10 @@ int inverse_from_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wl
     const bool fused = wlev == 4 && wrk::fused_ok(nx, ny, nz, -4) && !getenv("WR_NO_FUSED");
     if (fused) if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
     if (tm) HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    wrk::dequant_accum(fused ? c->d_scratch : d_fld, n, p, c->stream);
+    wrk::dequant_accum(fused ? c->pool->scratch : d_fld, n, p, c->stream);
     if (tm) HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    if (fused) wrk::transform_inv_fused(c->d_scratch, d_fld, c->d_lowbuf, nx, ny, nz, c->stream);
-    else wrk::transform(d_fld, c->d_scratch, nx, ny, nz, -wlev, c->stream);
+    if (fused) wrk::transform_inv_fused(c->pool->scratch, d_fld, c->pool->lowbuf, nx, ny, nz, c->stream);
+    else wrk::transform(d_fld, c->pool->scratch, nx, ny, nz, -wlev, c->stream);
     if (tm) HIPCHK(hipEventRecord(c->ev_c, c->stream));
     return WR_OK;
 }
@@ -320,9 +355,11 @@ int wr_ctx_create(wr_ctx** out, int device, void* hip_stream)
     if (e != hipSuccess || ndev < 1)
         return fail(WR_ERR_HIP, std::string("no usable HIP device (") + hipGetErrorString(e) +
                                     "): libwaverange_amd has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(WR_ERR_ARG, "device index out of range");
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(WR_ERR_ARG, "device index out of range");
     wr_ctx* c = new wr_ctx;
     c->device = device;
+    c->pool = &g_pools[device];
+    { std::lock_guard<std::mutex> lk(g_pools_mu); c->pool->users++; }
     HIPCHK(hipSetDevice(device));
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -347,15 +384,28 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy);
-    (void)hipFree(c->d_scratch); (void)hipFree(c->d_planes); (void)hipFree(c->d_field); (void)hipFree(c->d_lowbuf); (void)hipFree(c->d_cutoff);
+    (void)hipFree(c->d_field); (void)hipFree(c->d_cutoff);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
-    (void)hipHostFree(c->h_result); (void)hipFree(c->d_hist); (void)hipHostFree(c->h_hist);
-    for (int l = 0; l < WR_NLAYMAX; l++) { (void)hipHostFree(c->h_plane[l]); free(c->enc_buf[l]); }
+    (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_hist);
+    for (int l = 0; l < WR_NLAYMAX; l++) {
+        if (c->h_plane[l]) { if (c->h_plane_pinned[l]) (void)hipHostFree(c->h_plane[l]); else free(c->h_plane[l]); }
+        free(c->enc_buf[l]);
+    }
     for (int i = 0; i < WR_NLAYMAX; i++) { (void)hipEventDestroy(c->ev_plane[i]); (void)hipEventDestroy(c->ev_copy[i]); }
     (void)hipEventDestroy(c->ev_a); (void)hipEventDestroy(c->ev_b);
     (void)hipEventDestroy(c->ev_c); (void)hipEventDestroy(c->ev_d);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->copy);
+    {   // the last context on a device releases the shared work space
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        DevPool* p = c->pool;
+        if (--p->users == 0) {
+            std::lock_guard<std::mutex> ph(p->phase);
+            (void)hipFree(p->scratch); (void)hipFree(p->planes); (void)hipFree(p->lowbuf); (void)hipFree(p->hist);
+            p->scratch = nullptr; p->planes = nullptr; p->lowbuf = nullptr; p->hist = nullptr;
+            p->scratch_elems = p->planes_bytes = p->lowbuf_elems = p->hist_elems = 0;
+        }
+    }
     delete c;
 }
 
@@ -402,7 +452,9 @@ int wr_dev_download(wr_ctx* c, void* dst, const void* src, size_t bytes)
 int wr_dev_copy(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;
+    PhaseLock ph(c->pool->phase);  // a device phase like any other: keeps it off other contexts' transforms
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return WR_OK;
 }
 
@@ -423,10 +475,12 @@ int wr_dev_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl)
     if (int rc = ctx_bind(c)) return rc;
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     double* coef = nullptr;
+    PhaseLock ph(c->pool->phase);
     if (int rc = forward_transform(c, d_fld, nx, ny, nz, lvl, &coef)) return rc;  // handles lvl < 0 too
     if (coef != d_fld)
         HIPCHK(hipMemcpyAsync(d_fld, coef, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));  // the shared work space is released with the lock
     return WR_OK;
 }
 
@@ -584,6 +638,7 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     if ((uintptr_t)d_planes & 15) return fail(WR_ERR_ARG, "plane buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> lk(c->mu);
+    PhaseLock ph(c->pool->phase);
     Cutoff cut; cut.vec = &tolrel;
     int rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, d_planes, info, nullptr,
                                 [](unsigned, bool) { return WR_OK; });
@@ -605,6 +660,7 @@ int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const
         return WR_OK;
     }
     if (info->nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
+    PhaseLock ph(c->pool->phase);
     if (int rc = ensure_scratch(c, n)) return rc;
     wrk::DequantParams p;
     memset(&p, 0, sizeof p);
@@ -649,12 +705,9 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     const size_t n = (size_t)nx * ny * nz;
     const size_t pitch = wr_plane_pitch(n);
     wr_timings local; memset(&local, 0, sizeof local);
-    // device + pinned plane buffers for the worst case are grown lazily, plane by plane
-    if (int rc = ensure_planes(c, pitch * WR_NLAYMAX)) return rc;
     // per-60000-symbol-block byte histograms, counted on the GPU next to the quantizer and shipped
     // with the plane, so that the host coder starts every block with its model ready
     const size_t hist_per_plane = (n / wrrc::kBlock + 1) * 256;
-    if (int rc = ensure_hist(c, hist_per_plane * WR_NLAYMAX)) return rc;
 
     std::vector<std::thread> workers;
     size_t lens[WR_NLAYMAX] = {0};
@@ -664,26 +717,25 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     const int dev = c->device;
     double t_gpu_done = 0;
 
-    auto on_plane = [&](unsigned l, bool) -> int {
-        // plane l: device -> pinned host on the copy stream, then its own coder thread
-        HIPCHK(hipStreamWaitEvent(c->copy, c->ev_plane[l], 0));
-        wrk::block_histograms(c->d_planes + l * pitch, n, c->d_hist + l * hist_per_plane, c->copy);
-        HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, c->d_hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
-                              hipMemcpyDeviceToHost, c->copy));
-        if (int rc = ensure_host_plane(c, (int)l, pitch)) return rc;
-        if (int rc = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return rc;
-        HIPCHK(hipMemcpyAsync(c->h_plane[l], c->d_planes + l * pitch, n, hipMemcpyDeviceToHost, c->copy));
-        HIPCHK(hipEventRecord(c->ev_copy[l], c->copy));
-        workers.emplace_back([&, l]() {
-            (void)hipSetDevice(dev);
-            (void)hipEventSynchronize(c->ev_copy[l]);
-            sem.acquire();
-            const double t = now();
-            const uint8_t* q = c->h_plane[l];
-            lens[l] = wrrc::encode_plane(q, n, c->enc_buf[l], c->h_hist + l * hist_per_plane);
-            coder_s[l] = now() - t;
-            sem.release();
-            if (verbose()) {  // wrappers.cpp:401-409, 430
+    // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
+    // on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
+    // their number is known and each thread codes its group with the symbol loops interleaved.
+    const bool per_plane = g_threads >= WR_NLAYMAX;
+    auto code_group = [&](unsigned l0, unsigned l1) {
+        (void)hipSetDevice(dev);
+        (void)hipEventSynchronize(c->ev_copy[l1 - 1]);  // copies complete in plane order
+        sem.acquire();
+        const double t = now();
+        const uint8_t* syms[WR_NLAYMAX];
+        uint8_t* outs[WR_NLAYMAX];
+        const uint16_t* hs[WR_NLAYMAX];
+        for (unsigned l = l0; l < l1; l++) { syms[l - l0] = c->h_plane[l]; outs[l - l0] = c->enc_buf[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; }
+        wrrc::encode_planes((int)(l1 - l0), syms, n, outs, hs, lens + l0);
+        for (unsigned l = l0; l < l1; l++) coder_s[l] = now() - t;
+        sem.release();
+        if (verbose())  // wrappers.cpp:401-409, 430
+            for (unsigned l = l0; l < l1; l++) {
+                const uint8_t* q = c->h_plane[l];
                 unsigned lo = q[0], hi = q[0];
                 for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
                 char b[256];
@@ -691,18 +743,40 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
                          q[n / 2] * info->deps_vec[l] + info->minval_vec[l], (unsigned long)lens[l], (unsigned long)n);
                 logs[l] = b;
             }
-        });
+    };
+    auto on_plane = [&](unsigned l, bool) -> int {
+        // plane l: device -> pinned host on the copy stream
+        HIPCHK(hipStreamWaitEvent(c->copy, c->ev_plane[l], 0));
+        wrk::block_histograms(c->pool->planes + l * pitch, n, c->pool->hist + l * hist_per_plane, c->copy);
+        HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, c->pool->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
+                              hipMemcpyDeviceToHost, c->copy));
+        if (int rc = ensure_host_plane(c, (int)l, pitch)) return rc;
+        if (int rc = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_plane[l], c->pool->planes + l * pitch, n, hipMemcpyDeviceToHost, c->copy));
+        HIPCHK(hipEventRecord(c->ev_copy[l], c->copy));
+        if (per_plane) workers.emplace_back(code_group, l, l + 1);
         return WR_OK;
     };
     int rc;
+    double t_phase = 0;
     {
-        std::lock_guard<std::mutex> gpu(g_gpu_phase);
-        rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, c->d_planes, info, &local, on_plane);
-        // plane D2H copies run as blit kernels on this image: keep other contexts' kernels off the
-        // device until they are through (tens of ms; the coder threads start per plane regardless)
+        PhaseLock gpu(c->pool->phase);
+        t_phase = now();
+        rc = ensure_planes(c, pitch * WR_NLAYMAX);
+        if (!rc) rc = ensure_hist(c, hist_per_plane * WR_NLAYMAX);
+        if (!rc) rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, c->pool->planes, info, &local, on_plane);
+        // The phase ends when the planes are on the host: the plane buffer is shared with the other
+        // contexts on this device, and the D2H copies run as blit kernels on this image, which are
+        // better kept off other contexts' transforms (tens of ms; coder threads start per plane regardless)
         (void)hipStreamSynchronize(c->copy);
+        (void)hipStreamSynchronize(c->stream);
     }
     t_gpu_done = now();
+    if (!per_plane && rc == WR_OK && info->nlay) {
+        const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)g_threads);
+        for (unsigned g = 0; g < groups; g++)
+            workers.emplace_back(code_group, g * info->nlay / groups, (g + 1) * info->nlay / groups);
+    }
     for (auto& w : workers) w.join();
     if (rc) return rc;
     const double t_coded = now();
@@ -726,7 +800,7 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
         for (unsigned l = 0; l < info->nlay; l++) fputs(logs[l].c_str(), stdout);
     info->ntot_enc = total;
     local.total = now() - t0;
-    local.gpu = t_gpu_done - t0;
+    local.gpu = t_gpu_done - t_phase;  // without the wait for the device
     local.transfer = (t_coded - t_gpu_done) - local.rangecoder;
     if (local.transfer < 0) local.transfer = 0;
     if (tm) *tm = local;
@@ -753,9 +827,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     const int nlay = info->nlay;
     if (nlay < 1 || nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
     if (verbose()) printf("Range decoding...\n");
-    if (int rc = ensure_planes(c, pitch * nlay)) return rc;
     for (int l = 0; l < nlay; l++) if (int rc = ensure_host_plane(c, l, pitch)) return rc;
-    if (int rc = ensure_scratch(c, n)) return rc;
 
     size_t off[WR_NLAYMAX + 1] = {0};
     for (int l = 0; l < nlay; l++) off[l + 1] = off[l] + info->len_enc_vec[l];
@@ -764,17 +836,23 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     double coder_s[WR_NLAYMAX] = {0};
     std::vector<std::thread> workers;
     Sem sem(g_threads);
-    for (int l = 0; l < nlay; l++)
-        workers.emplace_back([&, l]() {
+    // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved
+    const int groups = std::min(nlay, g_threads);
+    for (int g = 0; g < groups; g++)
+        workers.emplace_back([&, g]() {
+            const int l0 = g * nlay / groups, l1 = (g + 1) * nlay / groups;
             sem.acquire();
             const double t = now();
-            got[l] = wrrc::decode_plane(data_enc + off[l], info->len_enc_vec[l], c->h_plane[l], n);
-            coder_s[l] = now() - t;
+            const uint8_t* ins[WR_NLAYMAX];
+            uint8_t* syms[WR_NLAYMAX];
+            for (int l = l0; l < l1; l++) { ins[l - l0] = data_enc + off[l]; syms[l - l0] = c->h_plane[l]; }
+            wrrc::decode_planes(l1 - l0, ins, info->len_enc_vec + l0, syms, n, got + l0);
+            for (int l = l0; l < l1; l++) coder_s[l] = now() - t;
             sem.release();
         });
+    for (auto& w : workers) w.join();
     int bad = -1;
     for (int l = 0; l < nlay; l++) {
-        workers[l].join();
         if (got[l] != n) bad = l;
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
     }
@@ -793,11 +871,16 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     wrk::DequantParams p;
     memset(&p, 0, sizeof p);
     p.nlay = nlay;
-    for (int l = 0; l < nlay; l++) { p.q[l] = c->d_planes + l * pitch; p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; }
+    for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; }
+    double t_phase = 0;
     {
-        std::lock_guard<std::mutex> gpu(g_gpu_phase);
+        PhaseLock gpu(c->pool->phase);
+        t_phase = now();
+        if (int rc = ensure_planes(c, pitch * nlay)) return rc;
+        if (int rc = ensure_scratch(c, n)) return rc;
+        for (int l = 0; l < nlay; l++) p.q[l] = c->pool->planes + l * pitch;
         for (int l = 0; l < nlay; l++)  // planes: pinned host -> device
-            HIPCHK(hipMemcpyAsync(c->d_planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->pool->planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, c->stream));
         if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -806,7 +889,7 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); local.quant_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_b, c->ev_c)); local.transform_ms = ms;
     local.total = now() - t0;
-    local.gpu = now() - t_coded;
+    local.gpu = now() - t_phase;  // without the wait for the device
     local.transfer = (t_coded - t0) - local.rangecoder;
     if (local.transfer < 0) local.transfer = 0;
     if (tm) *tm = local;
@@ -816,12 +899,21 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
 size_t wr_range_encode_bound(size_t n) { return wrrc::encode_bound(n); }
 size_t wr_range_encode(const unsigned char* sym, size_t n, unsigned char* out) { return wrrc::encode_plane(sym, n, out, nullptr); }
 size_t wr_range_decode(const unsigned char* in, size_t len, unsigned char* sym, size_t n) { return wrrc::decode_plane(in, len, sym, n); }
+void wr_range_encode_multi(int count, const unsigned char* const* sym, size_t n, unsigned char* const* out, size_t* lens)
+{
+    wrrc::encode_planes(count, sym, n, out, nullptr, lens);
+}
+void wr_range_decode_multi(int count, const unsigned char* const* in, const size_t* len, unsigned char* const* sym, size_t n, size_t* produced)
+{
+    wrrc::decode_planes(count, in, len, sym, n, produced);
+}
 
 int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl, int reps, double* ms_out)
 {
     if (int rc = ctx_bind(c)) return rc;
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     if (reps < 1) return fail(WR_ERR_ARG, "reps < 1");
+    PhaseLock ph(c->pool->phase);
     if (int rc = ensure_scratch(c, (size_t)nx * ny * nz)) return rc;
     double* coef = nullptr;
     HIPCHK(hipEventRecord(c->ev_a, c->stream));

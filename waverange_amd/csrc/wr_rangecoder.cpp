@@ -12,6 +12,8 @@
 
 #include <string.h>
 
+#include <new>
+#include <utility>
 #include <vector>
 
 namespace wrrc {
@@ -24,7 +26,7 @@ constexpr int kShift = 23;                 // rangecod.c:127  CODE_BITS - 9
 constexpr int kExtra = 7;                  // rangecod.c:128  (CODE_BITS-2) % 8 + 1
 
 struct Enc {
-    uint32_t low = 0, range = kTop, nbytes = 0;
+    uint32_t low = 0, range = kTop;  // rangecod.c's bytecount is pos - 1 here
     uint8_t* out;
     size_t pos;
 
@@ -44,7 +46,6 @@ struct Enc {
             out[pos++] = (uint8_t)(low >> kShift);
             range <<= 8;
             low = (low << 8) & (kTop - 1);
-            nbytes++;
         }
     }
     // rangecod.c:217-229
@@ -68,7 +69,7 @@ struct Enc {
     size_t finish()
     {
         renorm();
-        nbytes += 5;
+        const uint32_t nbytes = (uint32_t)(pos - 1) + 5;
         uint32_t t = low >> kShift;
         if (!((low & (kBottom - 1)) < ((nbytes & 0xffffffu) >> 1))) t += 1;
         if (t > 0xff) carry();
@@ -93,7 +94,7 @@ inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry
     // most one byte shifted out per symbol) is written branch-free: the byte is stored
     // unconditionally and `pos` advances by 0 or 1.  Two rare cases keep a branch: a pending
     // carry at the moment a byte leaves, and a second shift (symbol probability < 1/256).
-    uint32_t low = e.low, range = e.range, nbytes = e.nbytes;
+    uint32_t low = e.low, range = e.range;
     uint8_t* out = e.out;
     size_t pos = e.pos;
     const uint32_t tot = TOT ? TOT : bs;
@@ -106,7 +107,6 @@ inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry
         }
         out[pos] = (uint8_t)(low >> kShift);
         pos += sh;
-        nbytes += sh;
         low = sh ? (low << 8) & (kTop - 1) : low;
         range = sh ? range << 8 : range;
         while (__builtin_expect(range <= kBottom, 0)) {
@@ -117,7 +117,6 @@ inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry
             out[pos++] = (uint8_t)(low >> kShift);
             range <<= 8;
             low = (low << 8) & (kTop - 1);
-            nbytes++;
         }
         const uint32_t r = range / tot;
         const uint32_t t = r * tab[c].lt;
@@ -125,7 +124,7 @@ inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry
         // lt + sy < tot holds for every symbol except the largest one present (rangecod.c:227)
         range = (c != top_sym) ? r * tab[c].sy : range - t;
     }
-    e.low = low; e.range = range; e.nbytes = nbytes; e.pos = pos;
+    e.low = low; e.range = range; e.pos = pos;
 }
 
 inline void histogram(const uint8_t* s, uint32_t bs, uint32_t* h)
@@ -147,34 +146,121 @@ size_t encode_bound(size_t n)
     return n + n / 32 + blocks * 520 + 1024;
 }
 
-size_t encode_plane(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hists)
+namespace {
+
+// Interleaved symbol loop for NS planes (full 60000-symbol blocks).  One plane's coder is a
+// serial dependency chain of ~11 cycles per symbol that leaves most of a core idle; NS
+// independent chains in one loop fill it.  Same statements per plane as encode_symbols.
+template <int NS>
+inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const SymEntry (*tabs)[256], const uint32_t* tops)
 {
-    // block loop of wrappers.cpp:85-128: a full final block is followed by an empty one
-    Enc e(out);
+    uint32_t low[NS], range[NS];
+    uint8_t* out[NS];
+    size_t pos[NS];
+    for (int k = 0; k < NS; k++) { low[k] = es[k]->low; range[k] = es[k]->range; out[k] = es[k]->out; pos[k] = es[k]->pos; }
+    for (uint32_t i = 0; i < kBlock; i++) {
+#pragma GCC unroll 8
+        for (int k = 0; k < NS; k++) {
+            const uint32_t c = ss[k][i];
+            const uint32_t sh = range[k] <= kBottom;
+            if (__builtin_expect(sh & (low[k] >> 31), 0)) {
+                size_t p = pos[k] - 1;
+                while (++out[k][p] == 0) p--;
+            }
+            out[k][pos[k]] = (uint8_t)(low[k] >> kShift);
+            pos[k] += sh;
+            low[k] = sh ? (low[k] << 8) & (kTop - 1) : low[k];
+            range[k] = sh ? range[k] << 8 : range[k];
+            while (__builtin_expect(range[k] <= kBottom, 0)) {
+                if (low[k] & kTop) {
+                    size_t p = pos[k] - 1;
+                    while (++out[k][p] == 0) p--;
+                }
+                out[k][pos[k]++] = (uint8_t)(low[k] >> kShift);
+                range[k] <<= 8;
+                low[k] = (low[k] << 8) & (kTop - 1);
+            }
+            const uint32_t r = range[k] / kBlock;
+            const uint32_t t = r * tabs[k][c].lt;
+            low[k] += t;
+            range[k] = (c != tops[k]) ? r * tabs[k][c].sy : range[k] - t;
+        }
+    }
+    for (int k = 0; k < NS; k++) { es[k]->low = low[k]; es[k]->range = range[k]; es[k]->pos = pos[k]; }
+}
+
+// block header of wrappers.cpp:85-113: "a block follows", then the 256 counts
+inline void encode_block_header(Enc& e, const uint8_t* s, uint32_t bs, const uint16_t* hist, SymEntry* tab, uint32_t* top_sym)
+{
+    e.freq(1, 1, 2);
+    uint32_t h[256];
+    if (hist) { for (int b = 0; b < 256; b++) h[b] = hist[b]; }
+    else histogram(s, bs, h);
+    uint32_t cum = 0, top = 0;
+    for (int b = 0; b < 256; b++) {
+        e.shift(1, h[b], 16);  // encode_short(count), rangecod.h:155
+        tab[b].lt = cum; tab[b].sy = h[b];
+        cum += h[b];
+        if (h[b]) top = (uint32_t)b;
+    }
+    *top_sym = top;
+}
+
+}  // namespace
+
+// The encoder's loop keeps five values per plane in registers; beyond three planes the spills cost more
+// than the interleaving gains (EPYC 9575F: 1 plane 380-500 Msym/s, 2: 700, 3: 680, 4: 560 in total).
+constexpr int kMaxEncStreams = 3;
+
+void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens)
+{
+    // block loop of wrappers.cpp:85-128: a full final block is followed by an empty one.  All
+    // planes of a field have the same length, hence the same block boundaries: they advance in
+    // lockstep, block by block.
+    if (count < 1) return;
+    if (count > kMaxEncStreams) {  // more planes than one loop interleaves well: two halves, one after the other
+        const int h = (count + 1) / 2;
+        encode_planes(h, sym, n, out, hists, lens);
+        encode_planes(count - h, sym + h, n, out + h, hists ? hists + h : nullptr, lens + h);
+        return;
+    }
+    Enc* es[kMaxStreams];
+    alignas(Enc) unsigned char store[kMaxStreams][sizeof(Enc)];
+    for (int k = 0; k < count; k++) es[k] = new (store[k]) Enc(out[k]);
+    SymEntry tabs[kMaxStreams][256];
+    uint32_t tops[kMaxStreams];
+    const uint8_t* ss[kMaxStreams];
     size_t done = 0, blk = 0;
     for (;; blk++) {
         const size_t left = n - done;
         const uint32_t bs = left < kBlock ? (uint32_t)left : kBlock;
-        const uint8_t* s = sym + done;
-        e.freq(1, 1, 2);  // "a block follows"
-        uint32_t h[256];
-        if (hists) { for (int b = 0; b < 256; b++) h[b] = hists[blk * 256 + b]; }
-        else histogram(s, bs, h);
-        SymEntry tab[256];
-        uint32_t cum = 0, top_sym = 0;
-        for (int b = 0; b < 256; b++) {
-            e.shift(1, h[b], 16);  // encode_short(count), rangecod.h:155
-            tab[b].lt = cum; tab[b].sy = h[b];
-            cum += h[b];
-            if (h[b]) top_sym = (uint32_t)b;
+        for (int k = 0; k < count; k++) {
+            ss[k] = sym[k] + done;
+            encode_block_header(*es[k], ss[k], bs, (hists && hists[k]) ? hists[k] + blk * 256 : nullptr, tabs[k], &tops[k]);
         }
-        if (bs == kBlock) encode_symbols<kBlock>(e, s, bs, tab, top_sym);
-        else if (bs) encode_symbols<0>(e, s, bs, tab, top_sym);
+        if (bs == kBlock) {
+            switch (count) {
+            case 1: encode_symbols<kBlock>(*es[0], ss[0], bs, tabs[0], tops[0]); break;
+            case 2: encode_symbols_multi<2>(es, ss, tabs, tops); break;
+            default: encode_symbols_multi<3>(es, ss, tabs, tops); break;
+            }
+        } else if (bs) {
+            for (int k = 0; k < count; k++) encode_symbols<0>(*es[k], ss[k], bs, tabs[k], tops[k]);
+        }
         done += bs;
         if (bs < kBlock) break;
     }
-    e.freq(1, 0, 2);  // "no more blocks"
-    return e.finish();
+    for (int k = 0; k < count; k++) {
+        es[k]->freq(1, 0, 2);  // "no more blocks"
+        lens[k] = es[k]->finish();
+    }
+}
+
+size_t encode_plane(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hists)
+{
+    size_t len = 0;
+    encode_planes(1, &sym, n, &out, &hists, &len);
+    return len;
 }
 
 namespace {
@@ -274,36 +360,226 @@ inline size_t decode_symbols(Dec& d, uint8_t* dst, size_t room, uint32_t bs, con
 
 }  // namespace
 
+namespace {
+
+constexpr uint32_t kPad = 512;                          // see decode_symbols
+constexpr uint32_t kBucketShift = 4;                    // 16 cumulative-frequency values per bucket
+constexpr uint32_t kBuckets = ((kBlock + kPad) >> kBucketShift) + 1;
+
+// Everything the symbol loop needs about one block of one plane.
+struct BlockModel {
+    SymEntry tab[256];
+    uint32_t top;       // largest symbol present: its interval is open-ended (rangecod.c:317,345-348)
+    uint32_t bs;
+    // the two most probable symbols, when together they hold >= 90 % of the block: they are recognised
+    // by comparing `low` with the ends of their intervals, without the division and the look-ups
+    // (mps_on == false: test disabled; sy[1] == 0: one symbol only)
+    bool mps_on;
+    uint32_t mps[2], mps_lt[2], mps_sy[2];
+    bool mps_is_top[2];
+    // bucket table: symbol of all 16 values [16 j, 16 j + 15] if they agree, else kMixed.  15 KB for four
+    // planes stays in L1, the four 60 KB lookup tables do not.  Used when < 2 % of the block
+    // falls into mixed buckets (each escape is a branch miss).
+    bool use_buckets;
+    uint16_t bucket[kBuckets];
+    uint8_t lookup[kBlock + kPad];
+};
+constexpr uint16_t kMixed = 0x100;
+
+void finish_model(BlockModel& m)
+{
+    for (int b = 0; b < 256; b++)
+        if (m.tab[b].sy) memset(m.lookup + m.tab[b].lt, b, m.tab[b].sy);
+    memset(m.lookup + m.bs, (int)m.top, kPad);
+    uint32_t b1 = 0, b2 = 256;
+    for (int b = 1; b < 256; b++)
+        if (m.tab[b].sy > m.tab[b1].sy) b1 = (uint32_t)b;
+    for (int b = 0; b < 256; b++)
+        if ((uint32_t)b != b1 && m.tab[b].sy && (b2 == 256 || m.tab[b].sy > m.tab[b2].sy)) b2 = (uint32_t)b;
+    const uint32_t sy2 = b2 < 256 ? m.tab[b2].sy : 0;
+    m.mps[0] = b1; m.mps_lt[0] = m.tab[b1].lt; m.mps_sy[0] = m.tab[b1].sy; m.mps_is_top[0] = b1 == m.top;
+    m.mps[1] = b2 & 255; m.mps_lt[1] = sy2 ? m.tab[b2].lt : 0; m.mps_sy[1] = sy2; m.mps_is_top[1] = sy2 && b2 == m.top;
+    m.mps_on = m.bs && ((uint64_t)(m.tab[b1].sy + sy2) * 10 >= (uint64_t)m.bs * 9);
+    uint32_t mixed = 0;
+    for (uint32_t j = 0; j < kBuckets; j++) {
+        const uint32_t lo = j << kBucketShift, hi = lo + (1u << kBucketShift) - 1;
+        const uint8_t a = m.lookup[lo < kBlock + kPad ? lo : kBlock + kPad - 1], z = m.lookup[hi < kBlock + kPad ? hi : kBlock + kPad - 1];
+        m.bucket[j] = (a == z) ? a : kMixed;  // symbols ascend with the cumulative frequency: equal ends = equal throughout
+        if (a != z && lo < m.bs) mixed += 1u << kBucketShift;
+    }
+    m.use_buckets = (uint64_t)mixed * 50 < m.bs;
+}
+
+// Symbol loop of NS planes, interleaved; needs, per plane, a full block, room for 60000 symbols
+// and at least 3 * 60000 + 8 unread stream bytes (a symbol pulls in at most 3 bytes), so the
+// loop carries no bounds checks.  One plane's decoder is a serial chain of ~45 cycles per symbol
+// (renormalise, range / tot, low / help, table look-ups, multiply) that leaves most of a core
+// idle; NS independent chains in one loop fill it.  Arithmetic per plane as in decode_symbols.
+// (The stream feeds `low` a continuous bit string that starts 7 bits into a byte:
+// held << EXTRA | next >> (8 - EXTRA), rangecod.c:297-299.)
+template <int NS, unsigned MPS>  // bit k of MPS: plane k's block has dominant symbols (BlockModel::mps_on)
+void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
+{
+    // Only low, range and the stream pointer live in registers per plane; everything else is read
+    // through the model pointer where it is needed (hoisting it costs more in spills than it saves).
+    uint32_t low[NS], range[NS];
+    const uint8_t* p[NS];
+    for (int k = 0; k < NS; k++) { low[k] = ds[k]->low; range[k] = ds[k]->range; p[k] = ds[k]->in + ds[k]->pos; }
+    for (uint32_t i = 0; i < kBlock; i++) {
+#pragma GCC unroll 8
+        for (int k = 0; k < NS; k++) {
+            const BlockModel* const m = ms[k];
+            uint32_t lw = low[k], rg = range[k];
+            const uint8_t* q = p[k];
+            {   // first renormalisation step without a branch
+                // (shifts by 0 or 8 rather than selects: compilers turn selects into branches here, and
+                // this one is badly predicted on planes of medium entropy)
+                const uint32_t sh = rg <= kBottom;
+                const uint32_t bits = ((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff;
+                lw = (lw << (8 * sh)) | (bits & (0u - sh));
+                rg <<= 8 * sh;
+                q += sh;
+            }
+            while (__builtin_expect(rg <= kBottom, 0)) {
+                lw = (lw << 8) | (((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff);
+                rg <<= 8;
+                q++;
+            }
+            const uint32_t help = rg / kBlock;
+            uint32_t c;
+            bool hit = false;
+            if (MPS >> k & 1) {
+                // cf = low / help lies in a symbol's interval [lt, lt + sy)  <=>  low - help * lt < help * sy;
+                // the new range is that width, or what is left of range for the largest symbol (rangecod.c:345-348)
+                const uint32_t a0 = help * m->mps_lt[0], a1 = help * m->mps_lt[1];
+                const uint32_t w0 = m->mps_is_top[0] ? rg - a0 : help * m->mps_sy[0];
+                const uint32_t w1 = m->mps_is_top[1] ? rg - a1 : help * m->mps_sy[1];
+                const bool in0 = lw - a0 < w0, in1 = lw - a1 < w1;
+                if (__builtin_expect(in0 | in1, 1)) {
+                    hit = true;
+                    c = in0 ? m->mps[0] : m->mps[1];
+                    lw -= in0 ? a0 : a1;
+                    rg = in0 ? w0 : w1;
+                }
+            }
+            if (!hit) {
+                const uint32_t cf = lw / help;
+                if (m->use_buckets) {
+                    const uint32_t e = m->bucket[cf >> kBucketShift];
+                    c = e;
+                    if (__builtin_expect(e == kMixed, 0)) c = m->lookup[cf];
+                } else
+                    c = m->lookup[cf];
+                const uint32_t t = help * m->tab[c].lt;
+                lw -= t;
+                rg = (c != m->top) ? help * m->tab[c].sy : rg - t;
+            }
+            dst[k][i] = (uint8_t)c;
+            low[k] = lw; range[k] = rg; p[k] = q;
+        }
+    }
+    for (int k = 0; k < NS; k++) { ds[k]->low = low[k]; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
+}
+
+using MultiFn = void (*)(Dec* const*, uint8_t* const*, const BlockModel* const*);
+template <int NS, unsigned... M>
+constexpr MultiFn multi_entry(unsigned mask, std::integer_sequence<unsigned, M...>)
+{
+    constexpr MultiFn table[] = {&decode_symbols_multi<NS, M>...};
+    return table[mask];
+}
+inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
+{
+    unsigned mask = 0;
+    for (int k = 0; k < count; k++) mask |= (ms[k]->mps_on ? 1u : 0u) << k;
+    switch (count) {
+    case 1: multi_entry<1>(mask, std::make_integer_sequence<unsigned, 2>())(ds, dst, ms); break;
+    case 2: multi_entry<2>(mask, std::make_integer_sequence<unsigned, 4>())(ds, dst, ms); break;
+    case 3: multi_entry<3>(mask, std::make_integer_sequence<unsigned, 8>())(ds, dst, ms); break;
+    default: multi_entry<4>(mask, std::make_integer_sequence<unsigned, 16>())(ds, dst, ms); break;
+    }
+}
+
+}  // namespace
+
+void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced)
+{
+    // wrappers.cpp:153-224, the planes advancing block by block in lockstep
+    if (count < 1) return;
+    if (count > kMaxStreams) {
+        decode_planes(kMaxStreams, in, len, sym, n, produced);
+        decode_planes(count - kMaxStreams, in + kMaxStreams, len + kMaxStreams, sym + kMaxStreams, n, produced + kMaxStreams);
+        return;
+    }
+    Dec* ds[kMaxStreams];
+    alignas(Dec) unsigned char store[kMaxStreams][sizeof(Dec)];
+    std::vector<BlockModel> models((size_t)count);
+    const BlockModel* ms[kMaxStreams];
+    bool live[kMaxStreams], failed[kMaxStreams];
+    uint8_t* dst[kMaxStreams];
+    std::vector<uint8_t> tails[kMaxStreams];
+    constexpr size_t kMargin = 3 * (size_t)kBlock + 8;  // a symbol pulls in at most 3 bytes
+    for (int k = 0; k < count; k++) {
+        ds[k] = new (store[k]) Dec(in[k], len[k]);
+        ms[k] = &models[k];
+        produced[k] = 0;
+        live[k] = true; failed[k] = false;
+    }
+    for (;;) {
+        int nlive = 0;
+        bool fast = true;
+        for (int k = 0; k < count; k++) {
+            if (!live[k]) { fast = false; continue; }
+            Dec& d = *ds[k];
+            BlockModel& m = models[k];
+            if (!d.culfreq(2)) { live[k] = false; fast = false; d.renorm(); continue; }  // done_decoding, rangecod.c:371-373
+            d.update(1, 1, 2);
+            uint32_t bs = 0, top_sym = 0;
+            for (int b = 0; b < 256; b++) {
+                uint32_t c = d.culshift(16) & 0xffffu;  // decode_short, rangecod.c:362-366
+                d.update(1, c, 1u << 16);
+                m.tab[b].lt = bs; m.tab[b].sy = c;
+                bs += c;
+                if (c) top_sym = (uint32_t)b;
+            }
+            if (bs > kBlock) { live[k] = false; failed[k] = true; fast = false; continue; }  // not a WaveRange stream (defs.h:36)
+            m.top = top_sym; m.bs = bs;
+            finish_model(m);
+            dst[k] = sym[k] + (produced[k] < n ? produced[k] : n);
+            nlive++;
+            if (d.pos + kMargin > d.len && tails[k].empty() && d.pos >= 1 && d.pos <= d.len) {
+                // near the end of the stream: continue on a zero-padded copy of the rest (reading past
+                // the end yields zeros, Dec::get), so that the unchecked loop stays usable
+                tails[k].assign(d.len - (d.pos - 1) + kMargin, 0);
+                memcpy(tails[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
+                d.in = tails[k].data(); d.len = tails[k].size(); d.pos = 1;
+            }
+            if (bs != kBlock || produced[k] + kBlock > n || d.pos + kMargin > d.len) fast = false;
+        }
+        if (!nlive) break;
+        if (fast) {
+            decode_block_multi(count, ds, dst, ms);
+            for (int k = 0; k < count; k++) produced[k] += kBlock;
+            continue;
+        }
+        for (int k = 0; k < count; k++) {
+            if (!live[k]) continue;
+            const BlockModel& m = models[k];
+            const size_t room = produced[k] < n ? n - produced[k] : 0;
+            if (m.bs == kBlock) decode_symbols<kBlock>(*ds[k], dst[k], room, m.bs, m.tab, m.lookup, m.top);
+            else if (m.bs) decode_symbols<0>(*ds[k], dst[k], room, m.bs, m.tab, m.lookup, m.top);
+            produced[k] += m.bs;
+            if (ds[k]->pos > ds[k]->len + 8) { live[k] = false; failed[k] = true; }  // ran far past the end: corrupt stream
+        }
+    }
+    for (int k = 0; k < count; k++)
+        if (failed[k]) produced[k] = (size_t)-1;
+}
+
 size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
 {
-    // wrappers.cpp:153-224
-    Dec d(in, len);
     size_t produced = 0;
-    constexpr uint32_t kPad = 512;
-    std::vector<uint8_t> lookup(kBlock + kPad);
-    while (d.culfreq(2)) {
-        d.update(1, 1, 2);
-        SymEntry tab[256];
-        uint32_t bs = 0, top_sym = 0;
-        for (int b = 0; b < 256; b++) {
-            uint32_t c = d.culshift(16) & 0xffffu;  // decode_short, rangecod.c:362-366
-            d.update(1, c, 1u << 16);
-            tab[b].lt = bs; tab[b].sy = c;
-            bs += c;
-            if (c) top_sym = (uint32_t)b;
-        }
-        if (bs > kBlock) return (size_t)-1;  // not a WaveRange stream (blocks hold at most 60000 symbols, defs.h:36)
-        for (int b = 0; b < 256; b++)
-            if (tab[b].sy) memset(lookup.data() + tab[b].lt, b, tab[b].sy);
-        memset(lookup.data() + bs, (int)top_sym, kPad);  // see decode_symbols
-        const size_t room = produced < n ? n - produced : 0;
-        uint8_t* dst = sym + (produced < n ? produced : n);
-        if (bs == kBlock) decode_symbols<kBlock>(d, dst, room, bs, tab, lookup.data(), top_sym);
-        else if (bs) decode_symbols<0>(d, dst, room, bs, tab, lookup.data(), top_sym);
-        produced += bs;
-        if (d.pos > len + 8) return (size_t)-1;  // ran far past the end: corrupt stream
-    }
-    d.renorm();  // done_decoding, rangecod.c:371-373
+    decode_planes(1, &in, &len, &sym, n, &produced);
     return produced;
 }
 

@@ -3,7 +3,8 @@
 // Bit-exact with the reference's per-plane stream: Schindler's rngcod13 primitives
 // (reference src/rangecod/rangecod.c:170-404) driven by the 60000-symbol block model of
 // src/core/wrappers.cpp:68-224.  The range coder stays on the host by design (it is one
-// serial recurrence per plane); planes are coded concurrently, one thread each.
+// serial recurrence per plane); planes are coded concurrently: one thread each, or several
+// planes interleaved in one thread's loop when cores are scarcer than planes.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -11,6 +12,7 @@
 namespace wrrc {
 
 constexpr uint32_t kBlock = 60000;  // reference src/core/defs.h:36
+constexpr int kMaxStreams = 4;      // planes interleaved in one symbol loop
 
 // upper bound on the stream length for n symbols
 size_t encode_bound(size_t n);
@@ -20,8 +22,17 @@ size_t encode_bound(size_t n);
 // Returns the stream length.
 size_t encode_plane(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hists);
 
+// `count` planes of n symbols each on the calling thread, their symbol loops interleaved in
+// groups of up to kMaxStreams (same bytes as encode_plane on each).  hists may be null, and so
+// may its entries.
+void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens);
+
 // Decode a stream into exactly n symbols.  Returns the number of symbols the stream held
 // (== n for a well-formed stream; never writes more than n symbols, never reads past len).
 size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n);
+
+// `count` streams of n symbols each on the calling thread, interleaved like encode_planes;
+// produced[k] as decode_plane's return value, (size_t)-1 for a stream that is not decodable.
+void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced);
 
 }  // namespace wrrc
