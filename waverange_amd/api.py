@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwaverange_amd.so")
+# WAVERANGE_AMD_LIB points at another build of the library (A/B runs of experimental builds)
+LIB_PATH = os.environ.get("WAVERANGE_AMD_LIB") or os.path.join(HERE, "libwaverange_amd.so")
 NLAYMAX = 8
 
 _vp = C.c_void_p

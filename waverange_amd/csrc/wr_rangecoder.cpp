@@ -385,6 +385,12 @@ struct BlockModel {
     uint8_t lookup[kBlock + kPad];
 };
 constexpr uint16_t kMixed = 0x100;
+#ifndef WR_RC_MIXED_PCT
+#define WR_RC_MIXED_PCT 2
+#endif
+#ifndef WR_RC_MPS_PCT
+#define WR_RC_MPS_PCT 90
+#endif
 
 void finish_model(BlockModel& m)
 {
@@ -399,7 +405,7 @@ void finish_model(BlockModel& m)
     const uint32_t sy2 = b2 < 256 ? m.tab[b2].sy : 0;
     m.mps[0] = b1; m.mps_lt[0] = m.tab[b1].lt; m.mps_sy[0] = m.tab[b1].sy; m.mps_is_top[0] = b1 == m.top;
     m.mps[1] = b2 & 255; m.mps_lt[1] = sy2 ? m.tab[b2].lt : 0; m.mps_sy[1] = sy2; m.mps_is_top[1] = sy2 && b2 == m.top;
-    m.mps_on = m.bs && ((uint64_t)(m.tab[b1].sy + sy2) * 10 >= (uint64_t)m.bs * 9);
+    m.mps_on = m.bs && ((uint64_t)(m.tab[b1].sy + sy2) * 100 >= (uint64_t)m.bs * WR_RC_MPS_PCT);
     uint32_t mixed = 0;
     for (uint32_t j = 0; j < kBuckets; j++) {
         const uint32_t lo = j << kBucketShift, hi = lo + (1u << kBucketShift) - 1;
@@ -407,7 +413,7 @@ void finish_model(BlockModel& m)
         m.bucket[j] = (a == z) ? a : kMixed;  // symbols ascend with the cumulative frequency: equal ends = equal throughout
         if (a != z && lo < m.bs) mixed += 1u << kBucketShift;
     }
-    m.use_buckets = (uint64_t)mixed * 50 < m.bs;
+    m.use_buckets = (uint64_t)mixed * 100 < (uint64_t)m.bs * WR_RC_MIXED_PCT;
 }
 
 // Symbol loop of NS planes, interleaved; needs, per plane, a full block, room for 60000 symbols
