@@ -54,6 +54,40 @@ def measured_traffic(n):
     return best
 
 
+def _cgroup_number(path):
+    try:
+        with open(path) as fh:
+            return fh.read().split()
+    except OSError:
+        return None
+
+
+def fit_jobs(want, ntols, field_bytes, hbm_free):
+    """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
+    memory and the free HBM.  Returns (jobs, {what was found})."""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    cpus = float(len(os.sched_getaffinity(0)))
+    q = _cgroup_number("/sys/fs/cgroup/cpu.max")
+    if q and q[0] != "max":
+        cpus = min(cpus, float(q[0]) / float(q[1]))
+    cpus /= local_world
+    mem = None
+    try:
+        with open("/proc/meminfo") as fh:
+            mem = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]
+    except (OSError, IndexError):
+        pass
+    m = _cgroup_number("/sys/fs/cgroup/memory.max")
+    if m and m[0] != "max":
+        mem = min(mem, int(m[0])) if mem else int(m[0])
+    by_cpu = int(cpus // (2 * ntols))
+    by_mem = int(0.6 * mem / local_world // (1.4 * field_bytes * ntols)) if mem else want
+    by_hbm = int((0.92 * hbm_free - 3.3 * field_bytes) // (2 * field_bytes * ntols))
+    jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
+    return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / local_world / 2 ** 30, 1) if mem else None,
+                  "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
+
+
 def cpu_baseline(size, tols):
     """The reference itself (oracle/_ref, kind "reference") or, if absent, the oracle port,
     single thread, on a bounded sample of the same workload."""
@@ -136,6 +170,11 @@ def main():
             dist.all_reduce(t)
             torch.cuda.synchronize()
 
+    # How many fields in flight this rank can afford: two coder threads (encoder stage, decoder stage)
+    # and ~1.4 field sizes of host memory (pinned plane staging, coded streams; measured 1.32) per field, 2 field
+    # sizes of HBM per field plus the shared work space.  --jobs is the upper bound.
+    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0])
+
     # One lane per field of the batch (jobs x tolerance settings: independent jobs that run
     # concurrently on the one GPU; they all code this rank's synthetic field).  A lane is a two-stage pipeline -- encoder context and decoder
     # context, two coded-stream buffers in between -- so that step k+1's encode overlaps step k's
@@ -149,7 +188,7 @@ def main():
     ctx.sync()
     _, cap = api.setup_wr(n, n, n)
     lanes = []
-    for i, tol in enumerate(tols * args.jobs):
+    for i, tol in enumerate(tols * jobs):
         ce = ctx if i == 0 else api.Context(dev_index)
         cd = api.Context(dev_index)
         lanes.append(dict(tol=tol, enc=ce, dec=cd, work=ce.alloc(nelem * 8), rec=cd.alloc(nelem * 8),
@@ -245,7 +284,7 @@ def main():
                                    % (n, " and ".join("%g" % t for t in tols),
                                       "BASELINE configs[2]" if n == 1024 else "BASELINE configs[1]/[3] shape" if n == 512 else "parity-size run"),
                        "field_shards": world, "range_coder_threads": args.threads,
-                       "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": len(lanes), "pipeline": "encode(k+1) overlaps decode(k)",
+                       "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": len(lanes), "sizing": limits, "pipeline": "encode(k+1) overlaps decode(k)",
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(n),
@@ -266,6 +305,17 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:
+            # one field alone on the idle machine, a coder thread per plane: the latency a single
+            # encoding_wrap / decoding_wrap caller sees (outside the timed region)
+            api.set_threads(8)
+            ln = lanes[-1]
+            ln["enc"].copy(ln["work"], orig, nelem * 8)
+            enc1, te1 = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][0])
+            td1 = ln["dec"].decode(ln["rec"], shape, enc1)
+            out["single_field"] = {"tol": ln["tol"], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
+                                   "decode_s": round(td1["total"], 3),
+                                   "MBps": round(field_mb / (te1["total"] + td1["total"]), 1)}
+            api.set_threads(args.threads)
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols)
         print(json.dumps(out), flush=True)
     if dist is not None:
