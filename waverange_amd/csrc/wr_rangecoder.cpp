@@ -25,6 +25,28 @@ constexpr uint32_t kBottom = 0x00800000u;  // rangecod.c:129  Top >> 8
 constexpr int kShift = 23;                 // rangecod.c:127  CODE_BITS - 9
 constexpr int kExtra = 7;                  // rangecod.c:128  (CODE_BITS-2) % 8 + 1
 
+// cond ? a : b as a conditional move, whatever the compiler thinks of the predictability.  Used where the
+// condition is "which of the two dominant symbols came" (a coin flip on a two-symbol plane); the
+// "largest symbol present" tests stay branches, which predict well and keep the chain shorter
+// (measured on EPYC 9575F: cmov there costs the encoder 12 %).
+static inline uint32_t select_u32(uint32_t cond, uint32_t a, uint32_t b)
+{
+#if defined(__x86_64__)
+    __asm__("testl %1, %1\n\tcmovzl %2, %0" : "+r"(a) : "r"(cond), "r"(b) : "cc");
+    return a;
+#else
+    return cond ? a : b;
+#endif
+}
+// keeps the compiler from splitting `if (x | y)` into two branches
+static inline uint32_t opaque_u32(uint32_t v)
+{
+#if defined(__x86_64__)
+    __asm__("" : "+r"(v));
+#endif
+    return v;
+}
+
 struct Enc {
     uint32_t low = 0, range = kTop;  // rangecod.c's bytecount is pos - 1 here
     uint8_t* out;
@@ -460,12 +482,12 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
                 const uint32_t a0 = help * m->mps_lt[0], a1 = help * m->mps_lt[1];
                 const uint32_t w0 = m->mps_is_top[0] ? rg - a0 : help * m->mps_sy[0];
                 const uint32_t w1 = m->mps_is_top[1] ? rg - a1 : help * m->mps_sy[1];
-                const bool in0 = lw - a0 < w0, in1 = lw - a1 < w1;
-                if (__builtin_expect(in0 | in1, 1)) {
+                const uint32_t in0 = lw - a0 < w0, in1 = lw - a1 < w1;
+                if (__builtin_expect(opaque_u32(in0 | in1), 1)) {
                     hit = true;
-                    c = in0 ? m->mps[0] : m->mps[1];
-                    lw -= in0 ? a0 : a1;
-                    rg = in0 ? w0 : w1;
+                    c = select_u32(in0, m->mps[0], m->mps[1]);
+                    lw -= select_u32(in0, a0, a1);
+                    rg = select_u32(in0, w0, w1);
                 }
             }
             if (!hit) {
