@@ -3,7 +3,7 @@
 resident in HBM (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; % HBM
 roofline; L-inf vs tol").
 
-One step = one batch of jobs x len(tols) fields per GPU (default 4 x 2), each of them encoded (min/max,
+One step = one batch of jobs x len(tols) fields per GPU (default 5 x 2, fewer if the rank's CPUs or memory are short), each of them encoded (min/max,
 forward CDF-9/7, bit-plane quantizer on the GPU; planes D2H; rngcod13 range coder on the host)
 and decoded again (range decoder on the host; planes H2D; dequantise + inverse transform on
 the GPU).  The range coder is one serial recurrence per plane and runs on the host by design, so the
@@ -12,7 +12,7 @@ encoder and one decoder thread that code its 3-4 planes with interleaved symbol 
 fields are in flight to fill the cores.  Device phases of the fields serialise inside the library.
 value = field megabytes (10^6 B) round-tripped per second, whole job.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 4] [--threads 1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 5] [--threads 1]
 
 N > 1: one process per GPU (torch.distributed / RCCL for the timing barrier only); every rank
 codes its own independent field (seed 12345 + rank): weak scaling, no data-path collective.
@@ -80,7 +80,9 @@ def fit_jobs(want, ntols, field_bytes, hbm_free):
     m = _cgroup_number("/sys/fs/cgroup/memory.max")
     if m and m[0] != "max":
         mem = min(mem, int(m[0])) if mem else int(m[0])
-    by_cpu = int(cpus // (2 * ntols))
+    # 2 coder threads per field; an encoder thread idles a third of the time (decoding takes longer and
+    # sets the period of a lane), hence 1.25 threads per CPU
+    by_cpu = int(1.25 * cpus // (2 * ntols))
     by_mem = int(0.6 * mem / local_world // (1.4 * field_bytes * ntols)) if mem else want
     by_hbm = int((0.92 * hbm_free - 3.3 * field_bytes) // (2 * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
@@ -129,7 +131,7 @@ def main():
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=4, help="fields in flight per tolerance (a step codes jobs x tols fields)")
+    ap.add_argument("--jobs", type=int, default=5, help="fields in flight per tolerance (a step codes jobs x tols fields)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per encode/decode call; planes are interleaved when fewer than planes")
     args = ap.parse_args()
     tols = [float(t) for t in args.tols.split(",")]
