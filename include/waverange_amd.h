@@ -135,7 +135,9 @@ const char *wr_last_error(void);
 int wr_device_count(void);
 /* 0 = silent, 1 = the reference's progress lines on stdout (default; WR_QUIET=1 silences) */
 void wr_set_verbosity(int level);
-/* number of host range-coder threads (default: one per plane, WR_NLAYMAX max) */
+/* host range-coder threads per encode / decode call (default: one per plane; WR_THREADS=k in the
+ * environment sets the default).  With fewer threads than planes a thread codes several planes
+ * with interleaved symbol loops: less CPU time per field, more wall time for a single field. */
 void wr_set_threads(int nthreads);
 
 /* One context per (device, stream owner).  Work space (scratch field, plane buffers, pinned

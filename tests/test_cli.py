@@ -31,8 +31,8 @@ def sha_file(p):
     return hashlib.sha256(open(p, "rb").read()).hexdigest()
 
 
-def run_case(case, wrenc, wrdec, g):
-    env = dict(os.environ, WR_QUIET="1")
+def run_case(case, wrenc, wrdec, g, **extra_env):
+    env = dict(os.environ, WR_QUIET="1", **extra_env)
     with tempfile.TemporaryDirectory() as d:
         argv, stdin = cli_cases.write_inputs(case, d)
         assert sha_file(os.path.join(d, "data.bin")) == g["input_sha256"]
@@ -59,6 +59,15 @@ def test_our_cli_on_reference_codec(case, golden_cli):
 @pytest.mark.parametrize("case", sorted(cli_cases.CASES))
 def test_our_cli_on_gpu(case, golden_cli):
     run_case(case, os.path.join(BINDIR, "wrenc"), os.path.join(BINDIR, "wrdec"), golden_cli[case])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["1", "2"])
+def test_our_cli_on_gpu_with_few_coder_threads(threads, golden_cli):
+    """WR_THREADS < number of planes: the planes are coded in groups with interleaved symbol loops; the
+    files must not change."""
+    run_case("config1_64cube", os.path.join(BINDIR, "wrenc"), os.path.join(BINDIR, "wrdec"), golden_cli["config1_64cube"],
+             WR_THREADS=threads)
 
 
 @pytest.mark.gpu

@@ -1,10 +1,14 @@
 """Property-based checks (hypothesis) on the CPU side: product range coder == oracle range coder on
 arbitrary planes, stream anchors, transform round trips of the oracle on arbitrary small shapes."""
+import os
+
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
 from oracle.loader import Oracle
 from waverange_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 _o = Oracle()
 
@@ -42,3 +46,17 @@ def test_oracle_transform_round_trip(nx, ny, nz, seed):
     lhs = _o.cdf97_3d(f + 2.0 * g, 4)
     rhs = w + 2.0 * _o.cdf97_3d(g, 4)
     assert np.abs(lhs - rhs).max() <= 1e-11 * max(1.0, np.abs(lhs).max())
+
+
+def test_bench_batch_sizing():
+    """bench.py sizes its batch (fields in flight) to the rank's CPUs, host memory and free HBM."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fb = 1024 ** 3 * 8
+    jobs, lim = bench.fit_jobs(5, 2, fb, 288 * 10 ** 9)
+    assert 1 <= jobs <= 5 and jobs <= max(1, lim["jobs_by_cpu"]) and jobs <= max(1, lim["jobs_by_hbm"])
+    assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3.3 * fb) // (4 * fb))
+    # HBM nearly full: still one job, never zero
+    assert bench.fit_jobs(5, 2, fb, 40 * 10 ** 9)[0] == 1

@@ -39,7 +39,17 @@ thread_local std::string g_err;
 // Device phases of different contexts are serialised (they are tens of milliseconds); what
 // overlaps between concurrent encode/decode calls is the host range coding and the copies.
 int g_verbose = -1;  // -1: not initialised from the environment yet
-int g_threads = WR_NLAYMAX;
+int g_threads = -1;  // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
+
+int coder_threads()
+{
+    if (g_threads < 0) {
+        const char* e = getenv("WR_THREADS");
+        const int k = e ? atoi(e) : 0;
+        g_threads = k >= 1 ? k : WR_NLAYMAX;
+    }
+    return g_threads;
+}
 
 int verbose()
 {
@@ -713,14 +723,14 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     size_t lens[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
     std::string logs[WR_NLAYMAX];
-    Sem sem(g_threads);
+    Sem sem(coder_threads());
     const int dev = c->device;
     double t_gpu_done = 0;
 
     // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
     // on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
     // their number is known and each thread codes its group with the symbol loops interleaved.
-    const bool per_plane = g_threads >= WR_NLAYMAX;
+    const bool per_plane = coder_threads() >= WR_NLAYMAX;
     auto code_group = [&](unsigned l0, unsigned l1) {
         (void)hipSetDevice(dev);
         (void)hipEventSynchronize(c->ev_copy[l1 - 1]);  // copies complete in plane order
@@ -773,7 +783,7 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     }
     t_gpu_done = now();
     if (!per_plane && rc == WR_OK && info->nlay) {
-        const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)g_threads);
+        const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)coder_threads());
         for (unsigned g = 0; g < groups; g++)
             workers.emplace_back(code_group, g * info->nlay / groups, (g + 1) * info->nlay / groups);
     }
@@ -835,9 +845,9 @@ int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_
     size_t got[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
     std::vector<std::thread> workers;
-    Sem sem(g_threads);
+    Sem sem(coder_threads());
     // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved
-    const int groups = std::min(nlay, g_threads);
+    const int groups = std::min(nlay, coder_threads());
     for (int g = 0; g < groups; g++)
         workers.emplace_back([&, g]() {
             const int l0 = g * nlay / groups, l1 = (g + 1) * nlay / groups;
