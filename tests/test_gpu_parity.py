@@ -423,20 +423,21 @@ def test_concurrent_contexts_are_bit_exact(api, oracle):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("threads", [1, 2, 3])
-def test_grouped_coder_threads_same_bytes(ctx, api, oracle, threads):
+@pytest.mark.parametrize("threads,tol", [(1, 1e-7), (2, 1e-7), (3, 1e-7), (1, 1e-16), (3, 1e-16)])
+def test_grouped_coder_threads_same_bytes(ctx, api, oracle, threads, tol):
     """wr_set_threads(k) with k < nlay: the planes are coded in k groups with their symbol loops
     interleaved (wr_rangecoder.cpp encode_planes / decode_planes).  Streams and reconstruction must
     not depend on the grouping.  200x190x180 gives > 100 coding blocks per plane, so the unchecked
-    interleaved loops and the padded-tail path both run."""
+    interleaved loops and the padded-tail path both run; tol 1e-16 gives 8 planes (groups larger than
+    one loop interleaves are split)."""
     f = synth.field(180, 190, 200, seed=21)
-    e = oracle.encode(f, 1e-7)
-    assert e["nlay"] >= 3
+    e = oracle.encode(f, tol)
+    assert e["nlay"] >= (8 if tol < 1e-12 else 3)
     rec = oracle.decode(e, f.shape)
     api.set_threads(threads)
     try:
         buf = ctx.to_device(f)
-        enc, _ = ctx.encode(buf, f.shape, 1e-7)
+        enc, _ = ctx.encode(buf, f.shape, tol)
         assert enc["len_enc_vec"] == e["len_enc_vec"] and np.array_equal(enc["data"], e["data"])
         enc["data"] = enc["data"].copy()
         ctx.decode(buf, f.shape, enc)
