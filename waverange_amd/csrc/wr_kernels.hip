@@ -503,9 +503,53 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_dequant(double* __restrict__
     }
 }
 
+// Same sums, with the byte planes staged through LDS: a workgroup takes 4096 consecutive elements,
+// reads each plane's 4 KB with 16-byte loads, and every store instruction of a wave then covers
+// 1 KB of consecutive doubles (the direct form above moves 2 bytes per lane and load).
+constexpr int DQ_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, size_t nchunks, DequantParams p)
+{
+    __shared__ uint4 sq[8][DQ_CHUNK / 16];
+    const int t = threadIdx.x;
+    for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const size_t base = ch * DQ_CHUNK;
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+            if (l < p.nlay) sq[l][t] = reinterpret_cast<const uint4*>(p.q[l] + base)[t];
+        __syncthreads();
+        double2* a2 = reinterpret_cast<double2*>(acc + base);
+#pragma unroll
+        for (int j = 0; j < DQ_CHUNK / 512; j++) {
+            double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                if (l < p.nlay) {
+                    const uchar2 qq = reinterpret_cast<const uchar2*>(&sq[l][0])[j * 256 + t];
+                    a.x = a.x + ((double)qq.x * p.deps[l] + p.minval[l]);
+                    a.y = a.y + ((double)qq.y * p.deps[l] + p.minval[l]);
+                }
+            }
+            a2[j * 256 + t] = a;
+        }
+        __syncthreads();
+    }
+}
+
 void dequant_accum(double* acc, size_t n, const DequantParams& p, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_dequant, dim3(red_grid(n, 2)), dim3(WR_RED_THREADS), 0, st, acc, n, p);
+    bool aligned = ((uintptr_t)acc & 15) == 0;
+    for (int l = 0; l < p.nlay; l++) aligned = aligned && ((uintptr_t)p.q[l] & 15) == 0;
+    const size_t nchunks = aligned ? n / DQ_CHUNK : 0;
+    if (nchunks) {
+        const size_t g = nchunks < 256 * 8 ? nchunks : 256 * 8;
+        hipLaunchKernelGGL(k_dequant_lds, dim3((unsigned)g), dim3(256), 0, st, acc, nchunks, p);
+    }
+    const size_t done = nchunks * DQ_CHUNK;
+    if (done < n) {  // remainder (or everything, for unaligned plane pointers): direct form
+        DequantParams r = p;
+        for (int l = 0; l < p.nlay; l++) r.q[l] = p.q[l] + done;
+        hipLaunchKernelGGL(k_dequant, dim3(red_grid(n - done, 2)), dim3(WR_RED_THREADS), 0, st, acc + done, n - done, r);
+    }
 }
 
 // =====================================================================================
@@ -576,17 +620,38 @@ void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, i
     hipLaunchKernelGGL(k_synth, dim3(red_grid(total, 1)), dim3(WR_RED_THREADS), 0, st, out, nx, ny, nz, seed, z0, z1);
 }
 
-// one workgroup per 60000-symbol coding block: LDS histogram -> uint16[256]
+// one workgroup per 60000-symbol coding block: LDS histogram -> uint16[256].  Bit planes of a smooth
+// field are dominated by one value, so (a) a lane reads 16 symbols at once and adds a run of equal
+// ones with a single atomic, and (b) the lanes spread over 8 copies of the histogram, which bounds the
+// same-address serialisation of the LDS atomics.  (60000 = 16 * 3750; the plane base is 256-B aligned.)
 __global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, size_t n, uint16_t* __restrict__ hist)
 {
-    __shared__ unsigned int h[256];
-    h[threadIdx.x] = 0;
+    constexpr int COPIES = 8;
+    __shared__ unsigned int h[COPIES][256 + 1];  // +1: the copies start in different banks
+    for (int c = 0; c < COPIES; c++) h[c][threadIdx.x] = 0;
     __syncthreads();
     const size_t b0 = (size_t)blockIdx.x * 60000;
     const size_t b1 = (b0 + 60000 < n) ? b0 + 60000 : n;
-    for (size_t i = b0 + threadIdx.x; i < b1; i += 256) atomicAdd(&h[q[i]], 1u);
+    unsigned int* mine = h[threadIdx.x & (COPIES - 1)];
+    const size_t nvec = (b1 - b0) / 16;
+    const uint4* qv = reinterpret_cast<const uint4*>(q + b0);
+    for (size_t v = threadIdx.x; v < nvec; v += 256) {
+        const uint4 w = qv[v];
+        const unsigned int words[4] = {w.x, w.y, w.z, w.w};
+        unsigned int prev = words[0] & 0xff, run = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned int b = (words[k >> 2] >> (8 * (k & 3))) & 0xff;
+            if (b != prev) { atomicAdd(&mine[prev], run); prev = b; run = 0; }
+            run++;
+        }
+        atomicAdd(&mine[prev], run);
+    }
+    for (size_t i = b0 + nvec * 16 + threadIdx.x; i < b1; i += 256) atomicAdd(&mine[q[i]], 1u);
     __syncthreads();
-    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)h[threadIdx.x];
+    unsigned int tot = 0;
+    for (int c = 0; c < COPIES; c++) tot += h[c][threadIdx.x];
+    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)tot;
 }
 
 void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st)
