@@ -132,7 +132,8 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jobs", type=int, default=5, help="fields in flight per tolerance (a step codes jobs x tols fields)")
-    ap.add_argument("--threads", type=int, default=1, help="range-coder threads per encode/decode call; planes are interleaved when fewer than planes")
+    ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
+    ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
     args = ap.parse_args()
     tols = [float(t) for t in args.tols.split(",")]
     n = args.size
@@ -161,7 +162,7 @@ def main():
     import numpy as np
     from waverange_amd import api
     api.set_verbosity(0)
-    api.set_threads(args.threads)
+    api.set_threads(args.threads, args.enc_threads)
     if api.device_count() < 1:
         raise SystemExit("bench.py: no GPU visible (libwaverange_amd has no CPU fallback)")
 
@@ -285,7 +286,7 @@ def main():
             "config": {"workload": "single %d^3 fp64 field per GPU, tol=%s (%s)"
                                    % (n, " and ".join("%g" % t for t in tols),
                                       "BASELINE configs[2]" if n == 1024 else "BASELINE configs[1]/[3] shape" if n == 512 else "parity-size run"),
-                       "field_shards": world, "range_coder_threads": args.threads,
+                       "field_shards": world, "range_coder_threads": {"encode": args.enc_threads or args.threads, "decode": args.threads},
                        "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": len(lanes), "sizing": limits, "pipeline": "encode(k+1) overlaps decode(k)",
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -317,7 +318,7 @@ def main():
             out["single_field"] = {"tol": ln["tol"], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
                                    "decode_s": round(td1["total"], 3),
                                    "MBps": round(field_mb / (te1["total"] + td1["total"]), 1)}
-            api.set_threads(args.threads)
+            api.set_threads(args.threads, args.enc_threads)
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -139,6 +139,9 @@ void wr_set_verbosity(int level);
  * environment sets the default).  With fewer threads than planes a thread codes several planes
  * with interleaved symbol loops: less CPU time per field, more wall time for a single field. */
 void wr_set_threads(int nthreads);
+/* a different count for the encoder alone (0 = follow wr_set_threads, which also resets this): the
+ * encoder interleaves 2 planes as efficiently as 3-4, the decoder is at its best with 4 per thread */
+void wr_set_encoder_threads(int nthreads);
 
 /* One context per (device, stream owner).  Work space (scratch field, plane buffers, pinned
  * staging) is grown on demand and kept.  stream == NULL makes the context create its own. */

@@ -137,8 +137,10 @@ def set_verbosity(level):
     lib().wr_set_verbosity(int(level))
 
 
-def set_threads(n):
+def set_threads(n, encoder=0):
+    """coder threads per call; `encoder` > 0 gives the encoder its own count"""
     lib().wr_set_threads(int(n))
+    lib().wr_set_encoder_threads(int(encoder))
 
 
 # ---------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ thread_local std::string g_err;
 int g_verbose = -1;  // -1: not initialised from the environment yet
 int g_threads = -1;  // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
 
+int g_enc_threads = 0;  // 0: same as g_threads (wr_set_encoder_threads)
+
 int coder_threads()
 {
     if (g_threads < 0) {
@@ -50,6 +52,7 @@ int coder_threads()
     }
     return g_threads;
 }
+int encoder_threads() { return g_enc_threads > 0 ? g_enc_threads : coder_threads(); }
 
 int verbose()
 {
@@ -355,7 +358,8 @@ int wr_device_count(void)
 }
 
 void wr_set_verbosity(int level) { g_verbose = level ? 1 : 0; }
-void wr_set_threads(int nthreads) { g_threads = nthreads < 1 ? 1 : nthreads; }
+void wr_set_threads(int nthreads) { g_threads = nthreads < 1 ? 1 : nthreads; g_enc_threads = 0; }
+void wr_set_encoder_threads(int nthreads) { g_enc_threads = nthreads < 0 ? 0 : nthreads; }
 
 int wr_ctx_create(wr_ctx** out, int device, void* hip_stream)
 {
@@ -723,14 +727,14 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     size_t lens[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
     std::string logs[WR_NLAYMAX];
-    Sem sem(coder_threads());
+    Sem sem(encoder_threads());
     const int dev = c->device;
     double t_gpu_done = 0;
 
     // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
     // on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
     // their number is known and each thread codes its group with the symbol loops interleaved.
-    const bool per_plane = coder_threads() >= WR_NLAYMAX;
+    const bool per_plane = encoder_threads() >= WR_NLAYMAX;
     auto code_group = [&](unsigned l0, unsigned l1) {
         (void)hipSetDevice(dev);
         (void)hipEventSynchronize(c->ev_copy[l1 - 1]);  // copies complete in plane order
@@ -783,7 +787,7 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     }
     t_gpu_done = now();
     if (!per_plane && rc == WR_OK && info->nlay) {
-        const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)coder_threads());
+        const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)encoder_threads());
         for (unsigned g = 0; g < groups; g++)
             workers.emplace_back(code_group, g * info->nlay / groups, (g + 1) * info->nlay / groups);
     }
