@@ -125,7 +125,7 @@ def cpu_baseline(size, tols):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
