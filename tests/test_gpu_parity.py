@@ -445,3 +445,35 @@ def test_grouped_coder_threads_same_bytes(ctx, api, oracle, threads, tol):
         buf.free()
     finally:
         api.set_threads(8)
+
+
+def test_random_shapes_tolerances_and_field_kinds_vs_oracle(ctx, oracle):
+    """Seeded sweep over odd / thin / prime shapes, tolerances from 1e-2 to 1e-14 and several kinds of
+    field (smooth, noisy, piecewise constant, huge offset, tiny amplitude): coded bytes, header scalars
+    and reconstruction against the oracle."""
+    rs = np.random.RandomState(20261003)
+    for case in range(24):
+        nx, ny, nz = (int(rs.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 48, 64, 70])) for _ in range(3))
+        tol = float(10.0 ** -rs.randint(2, 15))
+        kind = case % 5
+        f = synth.field(nx, ny, nz, seed=1000 + case)
+        if kind == 1:
+            f = f + rs.standard_normal(f.shape) * 1e-3
+        elif kind == 2:
+            f = np.floor(f * 4.0) / 4.0
+        elif kind == 3:
+            f = f + 1.0e6
+        elif kind == 4:
+            f = f * 1.0e-12
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        want = oracle.encode(f, tol)
+        buf = ctx.to_device(f)
+        enc, _ = ctx.encode(buf, f.shape, tol)
+        tag = "case %d shape %s tol %g kind %d" % (case, (nx, ny, nz), tol, kind)
+        for k in ("tolabs", "midval", "halfspanval", "wlev", "nlay", "ntot_enc", "len_enc_vec"):
+            assert enc[k] == want[k], (tag, k)
+        assert np.array_equal(enc["data"], want["data"]), tag
+        enc["data"] = enc["data"].copy()
+        ctx.decode(buf, f.shape, enc)
+        assert bits_equal(buf.download(np.float64, f.size), oracle.decode(want, f.shape)), tag
+        buf.free()
