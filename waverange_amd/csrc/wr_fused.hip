@@ -269,19 +269,27 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             ylift(b);
             STAMP(4);
         }
-        // ---- z step: (a, b) is z-pair t  (waveletcdf97_3d.c:228-262)
+        // ---- z step: (a, b) is z-pair t  (waveletcdf97_3d.c:228-262).  Pair t-1 gets its first half
+        // (last1 / first1: it is the last / first pair), pair t-2 its second half and leaves.
+        const bool last1 = t - 1 >= m3 - 1, first1 = t - 1 <= 0, last2 = t - 2 >= m3 - 1, first2 = t - 2 <= 0;
+        if (last1) {  // the pair after the last one mirrors it
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = sr1[q];
+        }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
+            // Boundary forms by mirroring (c * (v + v) has the bits of (2 c) * v): one block-uniform select
+            // on an operand instead of the reference's second expression (waveletcdf97_3d.c:232,238,245,
+            // 251).  Pipeline fill / drain steps compute on zeros or stale values that never reach a store.
             double D1 = 0, S1 = 0;
             if (t >= 1 && t <= m3) {
-                const int j = t - 1;
-                D1 = (j < m3 - 1) ? dr1[q] + WR_ALPHA * (a[q] + sr1[q]) : dr1[q] + (WR_ALPHA * 2) * sr1[q];
-                S1 = (j > 0) ? sr1[q] + WR_BETA * (D1 + p1[q]) : sr1[q] + (WR_BETA * 2) * D1;
+                D1 = dr1[q] + WR_ALPHA * (a[q] + sr1[q]);
+                S1 = sr1[q] + WR_BETA * (D1 + (first1 ? D1 : p1[q]));
             }
             if (t >= 2) {
                 const int j = t - 2;
-                const double D2 = (j < m3 - 1) ? p1[q] + WR_GAMMA * (S1 + q1[q]) : p1[q] + (WR_GAMMA * 2) * q1[q];
-                const double S2 = (j > 0) ? q1[q] + WR_DELTA * (D2 + p2[q]) : q1[q] + (WR_DELTA * 2) * D2;
+                const double D2 = p1[q] + WR_GAMMA * ((last2 ? q1[q] : S1) + q1[q]);
+                const double S2 = q1[q] + WR_DELTA * (D2 + (first2 ? D2 : p2[q]));
                 const int yp = q >> 2;  // which of the two y-pairs
                 // wave-uniform plane bases + per-lane 32-bit offsets (saddr form).  Trading values
                 // between lane pairs for 16-byte stores was measured 3 % SLOWER (per-lane 64-bit
@@ -495,6 +503,9 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     for (int t = tb; t <= te; t++) {
         const int j = t - 2;
         const bool emit = j >= z0 && j < z1;  // block-uniform
+        // pair t enters (first: it has no left neighbour), pair t-1 gets its second half (last1 / first1:
+        // it is the last / the first pair), pair t-2 leaves (last2: it is the last pair)
+        const bool first = t == 0, last1 = t - 1 >= m3 - 1, first1 = t - 1 <= 0, last2 = j >= m3 - 1;
         STAMP(7);
         lds_barrier();  // the previous step's readers of zb are done
         STAMP(1);
@@ -503,26 +514,22 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         for (int k = 0; k < KCI; k++) {
             const int c = tid + INTHR * k;
             if (c < NCI) {
-                double lo[2] = {0, 0}, hi[2] = {0, 0};
-                if (t < m3) { lo[0] = rl[k].x; lo[1] = rl[k].y; hi[0] = rh[k].x; hi[1] = rh[k].y; }
+                // Boundary forms by mirroring: c * (v + v) has the bits of (2 c) * v, so "the missing neighbour
+                // is the other one" replaces the reference's second expression (waveletcdf97_3d.c:316,323,
+                // 329,335) with one block-uniform select on an operand.  Steps outside [0, m3) of the
+                // pipeline's fill and drain compute on stale operands; nothing they produce reaches an
+                // emitted plane (the selects below cut exactly those dependencies).
+                const double lo[2] = {rl[k].x, rl[k].y}, hi[2] = {rh[k].x, rh[k].y};
                 double ev[2], od[2];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    double d0 = 0, S1 = 0, D1 = 0, S2 = 0;
-                    if (t < m3) {
-                        const double s0 = lo[e] * WR_IZETA;
-                        d0 = hi[e] * WR_ZETA;
-                        S1 = (t > 0) ? s0 - WR_DELTA * (d0 + dprev[k][e]) : s0 - (WR_DELTA * 2) * d0;
-                    }
-                    if (t >= 1 && t <= m3) {
-                        const int jj = t - 1;
-                        D1 = (jj < m3 - 1) ? dprev[k][e] - WR_GAMMA * (S1 + s1prev[k][e])
-                                           : dprev[k][e] - (WR_GAMMA * 2) * s1prev[k][e];
-                        S2 = (jj > 0) ? s1prev[k][e] - WR_BETA * (D1 + d1prev[k][e]) : s1prev[k][e] - (WR_BETA * 2) * D1;
-                    }
+                    const double s0 = lo[e] * WR_IZETA;
+                    const double d0 = hi[e] * WR_ZETA;
+                    const double S1 = s0 - WR_DELTA * (d0 + (first ? d0 : dprev[k][e]));
+                    const double D1 = dprev[k][e] - WR_GAMMA * ((last1 ? s1prev[k][e] : S1) + s1prev[k][e]);
+                    const double S2 = s1prev[k][e] - WR_BETA * (D1 + (first1 ? D1 : d1prev[k][e]));
                     ev[e] = s2prev[k][e];
-                    od[e] = (j < m3 - 1) ? d1prev[k][e] - WR_ALPHA * (S2 + s2prev[k][e])
-                                         : d1prev[k][e] - (WR_ALPHA * 2) * s2prev[k][e];
+                    od[e] = d1prev[k][e] - WR_ALPHA * ((last2 ? s2prev[k][e] : S2) + s2prev[k][e]);
                     dprev[k][e] = d0; s1prev[k][e] = S1; d1prev[k][e] = D1; s2prev[k][e] = S2;
                 }
                 if (emit) { zb[c] = make_double2(ev[0], ev[1]); zb[NCI + c] = make_double2(od[0], od[1]); }
