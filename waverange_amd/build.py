@@ -17,7 +17,9 @@ ALIAS = os.path.join(HERE, "libwaverange.so")  # the reference's library name (d
 BIN = os.path.join(HERE, "bin")
 
 SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_rangecoder.cpp", "wr_compat.cpp"]
-CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"]}
+CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"],
+       # MSSG front-end (GrADS regular output, restart sets united / divided)
+       "wrenc_mssg": ["cli/mssg_enc.cpp", "cli/mssg_io.cpp"], "wrdec_mssg": ["cli/mssg_dec.cpp", "cli/mssg_io.cpp"]}
 # FluSI HDF5 front-end (libhdf5 is looked up at run time: HDF5_ROOT, the default path, /opt/conda)
 FLUSI = {"wrenc_flusi": ["cli/flusi_enc.cpp", "cli/flusi_h5.cpp"], "wrdec_flusi": ["cli/flusi_dec.cpp", "cli/flusi_h5.cpp"]}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
