@@ -67,9 +67,12 @@ def fit_jobs(want, ntols, field_bytes, hbm_free):
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     cpus = float(len(os.sched_getaffinity(0)))
-    q = _cgroup_number("/sys/fs/cgroup/cpu.max")
+    q = _cgroup_number("/sys/fs/cgroup/cpu.max")  # cgroup v2
     if q and q[0] != "max":
         cpus = min(cpus, float(q[0]) / float(q[1]))
+    q1, p1 = _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_period_us")  # v1
+    if q1 and p1 and float(q1[0]) > 0:
+        cpus = min(cpus, float(q1[0]) / float(p1[0]))
     cpus /= local_world
     mem = None
     try:
@@ -77,9 +80,10 @@ def fit_jobs(want, ntols, field_bytes, hbm_free):
             mem = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]
     except (OSError, IndexError):
         pass
-    m = _cgroup_number("/sys/fs/cgroup/memory.max")
-    if m and m[0] != "max":
-        mem = min(mem, int(m[0])) if mem else int(m[0])
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):  # cgroup v2, v1
+        m = _cgroup_number(path)
+        if m and m[0] != "max" and int(m[0]) < 1 << 60:
+            mem = min(mem, int(m[0])) if mem else int(m[0])
     # 2 coder threads per field; an encoder thread idles a third of the time (decoding takes longer and
     # sets the period of a lane), hence 1.25 threads per CPU
     by_cpu = int(1.25 * cpus // (2 * ntols))
