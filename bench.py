@@ -62,7 +62,24 @@ def _cgroup_number(path):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free):
+def take_cpu_share(local_rank, gpus_on_node):
+    """Pin this process (and the threads it starts later) to its GPU's share of the host CPUs: 1 / gpus_on_node
+    of the CPUs it may run on, the local_rank-th slice.  A rank then has the same host behind its GPU
+    whether 1 or 8 ranks run on the node (weak scaling measures GPUs, not how many idle cores one rank can
+    borrow).  No-op with a single visible GPU or when anything about it fails."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if gpus_on_node < 2 or len(allowed) < 2 * gpus_on_node:
+            return None
+        share = len(allowed) // gpus_on_node
+        mine = allowed[(local_rank % gpus_on_node) * share:(local_rank % gpus_on_node + 1) * share]
+        os.sched_setaffinity(0, mine)
+        return len(mine)
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -73,7 +90,8 @@ def fit_jobs(want, ntols, field_bytes, hbm_free):
     q1, p1 = _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_period_us")  # v1
     if q1 and p1 and float(q1[0]) > 0:
         cpus = min(cpus, float(q1[0]) / float(p1[0]))
-    cpus /= local_world
+    # with the affinity already cut down to this rank's share the count is per rank; quotas are per job
+    cpus = min(float(pinned_share), cpus) if pinned_share else cpus / local_world
     mem = None
     try:
         with open("/proc/meminfo") as fh:
@@ -180,7 +198,9 @@ def main():
     # How many fields in flight this rank can afford: two coder threads (encoder stage, decoder stage)
     # and ~1.4 field sizes of host memory (pinned plane staging, coded streams; measured 1.32) per field, 2 field
     # sizes of HBM per field plus the shared work space.  --jobs is the upper bound.
-    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0])
+    share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
+    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share)
+    limits["cpu_affinity_share"] = share
 
     # One lane per field of the batch (jobs x tolerance settings: independent jobs that run
     # concurrently on the one GPU; they all code this rank's synthetic field).  A lane is a two-stage pipeline -- encoder context and decoder

@@ -60,3 +60,20 @@ def test_bench_batch_sizing():
     assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3.3 * fb) // (4 * fb))
     # HBM nearly full: still one job, never zero
     assert bench.fit_jobs(5, 2, fb, 40 * 10 ** 9)[0] == 1
+
+
+def test_bench_cpu_share_pinning():
+    """bench.py pins a rank to its GPU's slice of the allowed CPUs on multi-GPU nodes (in a child process:
+    the affinity change must not leak into the test runner)."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; a = sorted(os.sched_getaffinity(0)); "
+            "n = bench.take_cpu_share(1, 2); b = sorted(os.sched_getaffinity(0)); "
+            "print(len(a), n, b == a[len(a)//2:2*(len(a)//2)] if n else b == a); "
+            "print(bench.take_cpu_share(0, 1))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split("\n")
+    total, share, ok = out[0].split()
+    assert ok == "True"
+    if int(total) >= 4:
+        assert int(share) == int(total) // 2
+    assert out[1] == "None"  # a single visible GPU: nothing to share
