@@ -69,9 +69,9 @@ def take_cpu_share(local_rank, gpus_on_node):
     borrow).  No-op with a single visible GPU or when anything about it fails."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        if gpus_on_node < 2 or len(allowed) < 2 * gpus_on_node:
+        share = len(allowed) // max(1, gpus_on_node)
+        if gpus_on_node < 2 or share < 8:  # a CPU set this small was sized for the job, not for the node
             return None
-        share = len(allowed) // gpus_on_node
         mine = allowed[(local_rank % gpus_on_node) * share:(local_rank % gpus_on_node + 1) * share]
         os.sched_setaffinity(0, mine)
         return len(mine)
