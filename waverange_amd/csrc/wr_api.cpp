@@ -780,7 +780,7 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
         if (!rc) rc = ensure_hist(c, hist_per_plane * WR_NLAYMAX);
         if (!rc) rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, c->pool->planes, info, &local, on_plane);
         // The phase ends when the planes are on the host: the plane buffer is shared with the other
-        // contexts on this device, and the D2H copies run as blit kernels on this image, which are
+        // contexts on this device, and with many contexts in a process the runtime runs the copies as blit kernels, which are
         // better kept off other contexts' transforms (tens of ms; coder threads start per plane regardless)
         (void)hipStreamSynchronize(c->copy);
         (void)hipStreamSynchronize(c->stream);
