@@ -4,7 +4,8 @@
 //   encoding_wrap : min/max -> forward transform -> bit-plane quantizer loop -> range coder
 //   decoding_wrap : range decoder -> dequantise-accumulate -> inverse transform
 // with the field resident in HBM, the quantized planes streamed to pinned host memory on a
-// copy stream, and one host range-coder thread per plane.  Compiled with hipcc, strict IEEE
+// copy stream, and host range-coder threads (one per plane, or fewer with the planes of a field
+// interleaved in one loop: wr_set_threads).  Compiled with hipcc, strict IEEE
 // (-ffp-contract=off): the scalar arithmetic on deps/aopt/bopt/tolabs below must round
 // exactly as wrappers.cpp:292-340 does.
 #include <float.h>
@@ -36,8 +37,9 @@ constexpr double kWavAccCoef = 1.75;
 constexpr unsigned long kSafetyBufferFactor = 1;
 
 thread_local std::string g_err;
-// Device phases of different contexts are serialised (they are tens of milliseconds); what
-// overlaps between concurrent encode/decode calls is the host range coding and the copies.
+// Device phases of the contexts on one GPU are serialised by the lock of that GPU's shared work space
+// (DevPool below; they are tens of milliseconds); what overlaps between concurrent encode/decode calls
+// is the host range coding.
 int g_verbose = -1;  // -1: not initialised from the environment yet
 int g_threads = -1;  // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
 
