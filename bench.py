@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- WaveRange hot path on MI355X: encode + decode of a 3-D fp64 field that is
-resident in HBM (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; % HBM
-roofline; L-inf vs tol").
+"""bench.py -- WaveRange hot path on MI355X: encode + decode of 3-D fp64 fields, host buffer to
+host buffer (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; % HBM roofline; L-inf vs
+tol"; SURVEY.md 8d(1): the reference API takes and returns host arrays).
 
-One step = one batch of jobs x len(tols) fields per GPU (default 5 x 2, fewer if the rank's CPUs or memory are short), each of them encoded (min/max,
-forward CDF-9/7, bit-plane quantizer on the GPU; planes D2H; rngcod13 range coder on the host)
-and decoded again (range decoder on the host; planes H2D; dequantise + inverse transform on
-the GPU).  The range coder is one serial recurrence per plane and runs on the host by design, so the
-whole-job rate is set by the host cores a GPU has (16 on this pool): every field in flight gets one
-encoder and one decoder thread that code its 3-4 planes with interleaved symbol loops, and enough
-fields are in flight to fill the cores.  Device phases of the fields serialise inside the library.
-value = field megabytes (10^6 B) round-tripped per second, whole job.
+One step = one batch of jobs x len(tols) fields per GPU (default 5 x 2, fewer if the rank's CPUs or memory
+are short).  Every field starts in a pinned host buffer and is encoded (upload; min/max, forward CDF-9/7,
+bit-plane quantizer on the GPU; planes D2H; rngcod13 range coder on the host -> coded bytes in host memory)
+and decoded again (range decoder on the host; planes H2D; dequantise + inverse transform on the GPU;
+download into another pinned host buffer): wr_encode_host / wr_decode_host, the functions the drop-in
+encoding_wrap / decoding_wrap run on.  The range coder is one serial recurrence per plane and runs on the
+host by design, so the whole-job rate is set by the host cores a GPU has (16 on this pool): every field in
+flight gets one encoder and one decoder thread that code its 3-4 planes with interleaved symbol loops, and
+enough fields are in flight to fill the cores.  The device stages of the fields (upload / kernels / download,
+three work-space slots per GPU) overlap with one another and with the host coding inside the library.
+value = field megabytes (10^6 B) round-tripped per second, whole job (all ranks).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 5] [--threads 1]
+                  [--resident]   (fields start and end in HBM instead: the round-1 measurement)
 
 N > 1: one process per GPU (torch.distributed / RCCL for the timing barrier only); every rank
 codes its own independent field (seed 12345 + rank): weak scaling, no data-path collective.
@@ -40,18 +44,32 @@ def box_elems(n, levels=4):
 
 def measured_traffic(n):
     """HBM bytes per transform from the committed PMC passes (profiles/rNN/traffic_<n>.json: rocprofv3
-    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950), mean of forward and inverse; None if not measured."""
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950), mean of forward and inverse.  Counters cannot be collected from inside this
+    process, so the figure is the latest committed one and carries its file name; (None, None) if absent."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%d.json" % n))):
         try:
             with open(f) as fh:
                 t = json.load(fh)
             best = 0.5 * (t["fwd"]["total_bytes"] + t["inv"]["total_bytes"])
+            src = os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return best
+    return best, src
+
+
+def committed_extra(name):
+    """A bench line committed under profiles/ (latest round), e.g. the resident-field variant of this run."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True):
+        try:
+            with open(f) as fh:
+                return json.load(fh), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    return None, None
 
 
 def _cgroup_number(path):
@@ -79,7 +97,7 @@ def take_cpu_share(local_rank, gpus_on_node):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None):
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -105,16 +123,33 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None):
     # 2 coder threads per field; an encoder thread idles a third of the time (decoding takes longer and
     # sets the period of a lane), hence 1.25 threads per CPU
     by_cpu = int(1.25 * cpus // (2 * ntols))
-    by_mem = int(0.6 * mem / local_world // (1.4 * field_bytes * ntols)) if mem else want
-    by_hbm = int((0.92 * hbm_free - 3.3 * field_bytes) // (2 * field_bytes * ntols))
+    # host memory per field in flight: pinned plane staging of the two contexts + coded streams (1.4 field sizes,
+    # measured 1.32) + the pinned output field (host-to-host mode); HBM: the work-space slots only, or
+    # (resident mode) two field buffers per lane on top
+    per_lane = (2.45 if host_mode else 1.4) * field_bytes
+    by_mem = int((0.8 * mem / local_world - (field_bytes if host_mode else 0)) // (per_lane * ntols)) if mem else want
+    by_hbm = want if host_mode else int((0.92 * hbm_free - 3 * 3.3 * field_bytes) // (2 * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / local_world / 2 ** 30, 1) if mem else None,
                   "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
 
 
-def cpu_baseline(size, tols):
-    """The reference itself (oracle/_ref, kind "reference") or, if absent, the oracle port,
-    single thread, on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(size, tols, ncores):
+    """The reference itself (oracle/_ref, kind "reference") or, if absent, the oracle port, on a bounded
+    sample of the same workload: one thread (the reference is single-threaded), then one independent field
+    per core on all cores of this rank (the "all host cores" figure)."""
+    import threading
     import numpy as np
     from oracle import loader
     from waverange_amd import synth
@@ -123,25 +158,43 @@ def cpu_baseline(size, tols):
     else:
         impl, kind = loader.Oracle(), "port"
     f = synth.field(size, size, size, seed=12345)
+
+    def roundtrip(fld):
+        for tol in tols:
+            enc = impl.encode(fld, tol)
+            impl.decode(enc, fld.shape)
+
     fd = os.dup(1)
     devnull = os.open(os.devnull, os.O_WRONLY)
     sys.stdout.flush()
     os.dup2(devnull, 1)  # the reference prints progress lines from C++
     try:
         t0 = time.time()
-        for tol in tols:
-            enc = impl.encode(f, tol)
-            impl.decode(enc, f.shape)
+        roundtrip(f)
         dt = time.time() - t0
+        # all cores: one field per core, every thread inside the C library (ctypes drops the GIL); a smaller
+        # field keeps this leg at the single-thread leg's duration
+        size_all = max(64, int(size * 0.8) // 16 * 16)
+        fa = synth.field(size_all, size_all, size_all, seed=12345)
+        ths = [threading.Thread(target=roundtrip, args=(fa,)) for _ in range(ncores)]
+        t1 = time.time()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt_all = time.time() - t1
     finally:
         sys.stdout.flush()
         os.dup2(fd, 1)
         os.close(devnull)
         os.close(fd)
     mb = len(tols) * f.nbytes / 1e6
-    return {"value": round(mb / dt, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+    mb_all = ncores * len(tols) * fa.nbytes / 1e6
+    return {"value": round(mb / dt, 2), "unit": "MB/s", "cores": 1, "kind": kind, "cpu": cpu_model(),
             "sample": "%d^3 fp64 field of the same generator, tols %s, encode+decode, %.1f s"
-                      % (size, ",".join("%g" % t for t in tols), dt)}
+                      % (size, ",".join("%g" % t for t in tols), dt),
+            "all_cores": {"value": round(mb_all / dt_all, 2), "unit": "MB/s", "cores": ncores,
+                          "sample": "one %d^3 field per core on %d cores at once, same tols, %.1f s" % (size_all, ncores, dt_all)}}
 
 
 def main():
@@ -156,9 +209,12 @@ def main():
     ap.add_argument("--jobs", type=int, default=5, help="fields in flight per tolerance (a step codes jobs x tols fields)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
+    ap.add_argument("--resident", action="store_true", help="fields start and end in HBM (round-1 measurement) instead of host buffers")
+    ap.add_argument("--slots", type=int, default=0, help="device work-space slots (0: library default)")
     args = ap.parse_args()
     tols = [float(t) for t in args.tols.split(",")]
     n = args.size
+    host_mode = not args.resident
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -187,6 +243,8 @@ def main():
     api.set_threads(args.threads, args.enc_threads)
     if api.device_count() < 1:
         raise SystemExit("bench.py: no GPU visible (libwaverange_amd has no CPU fallback)")
+    if args.slots:
+        api.set_device_slots(dev_index, args.slots)
 
     def barrier():
         torch.cuda.synchronize()
@@ -195,17 +253,17 @@ def main():
             dist.all_reduce(t)
             torch.cuda.synchronize()
 
-    # How many fields in flight this rank can afford: two coder threads (encoder stage, decoder stage)
-    # and ~1.4 field sizes of host memory (pinned plane staging, coded streams; measured 1.32) per field, 2 field
-    # sizes of HBM per field plus the shared work space.  --jobs is the upper bound.
+    # How many fields in flight this rank can afford: two coder threads (encoder stage, decoder stage) and
+    # ~2.45 field sizes of host memory per field (pinned plane staging, coded streams, the pinned output field).
+    # --jobs is the upper bound.
     share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
-    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share)
+    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode)
     limits["cpu_affinity_share"] = share
 
-    # One lane per field of the batch (jobs x tolerance settings: independent jobs that run
-    # concurrently on the one GPU; they all code this rank's synthetic field).  A lane is a two-stage pipeline -- encoder context and decoder
-    # context, two coded-stream buffers in between -- so that step k+1's encode overlaps step k's
-    # decode: device phases of all contexts serialise inside the library, host range coding overlaps.
+    # One lane per field of the batch (jobs x tolerance settings: independent jobs that run concurrently on
+    # the one GPU; they all code this rank's synthetic field).  A lane is a two-stage pipeline -- encoder
+    # context and decoder context, two coded-stream buffers in between -- so that step k+1's encode overlaps
+    # step k's decode: device stages of all contexts are scheduled inside the library, host range coding overlaps.
     import threading
     ctx = api.Context(dev_index)
     shape = (n, n, n)
@@ -214,16 +272,34 @@ def main():
     ctx.synth_field(orig, n, n, n, 12345 + rank)
     ctx.sync()
     _, cap = api.setup_wr(n, n, n)
+
+    def host_field():
+        try:
+            return api.pinned_array(shape)
+        except api.WaveRangeError:  # no pinned memory left: pageable works too (staged by the runtime)
+            return np.empty(shape, dtype=np.float64)
+
+    h_in = None
+    if host_mode:
+        h_in = host_field()
+        api._check(api.lib().wr_dev_download(ctx.h, h_in.ctypes.data, orig.ptr, nelem * 8))
+        orig.free()
+        orig = None
     lanes = []
     for i, tol in enumerate(tols * jobs):
         ce = ctx if i == 0 else api.Context(dev_index)
         cd = api.Context(dev_index)
-        lanes.append(dict(tol=tol, enc=ce, dec=cd, work=ce.alloc(nelem * 8), rec=cd.alloc(nelem * 8),
-                          data=[np.empty(cap, dtype=np.uint8) for _ in range(2)]))
+        ln = dict(tol=tol, enc=ce, dec=cd, data=[np.empty(cap, dtype=np.uint8) for _ in range(2)])
+        if host_mode:
+            ln["out"] = host_field()
+        else:
+            ln["work"], ln["rec"] = ce.alloc(nelem * 8), cd.alloc(nelem * 8)
+        lanes.append(ln)
 
     stats = {t: {} for t in tols}
-    acc = {"fwd_ms": [], "inv_ms": [], "quant_ms": [], "dequant_ms": [], "enc_s": [], "dec_s": [],
-           "enc_rc_s": [], "dec_rc_s": [], "enc_gpu_s": [], "dec_gpu_s": []}
+    keys = ("fwd_ms", "inv_ms", "quant_ms", "dequant_ms", "minmax_ms", "enc_s", "dec_s", "enc_rc_s", "dec_rc_s", "enc_gpu_s",
+            "dec_gpu_s", "enc_wait_s", "dec_wait_s", "enc_h2d_ms", "enc_d2h_ms", "dec_h2d_ms", "dec_d2h_ms", "nlay")
+    acc = {k: [] for k in keys}
     lock = threading.Lock()
     errors = []
 
@@ -239,8 +315,11 @@ def main():
                 try:
                     for k in range(nsteps):
                         free[k & 1].acquire()
-                        ln["enc"].copy(ln["work"], orig, nelem * 8)
-                        enc, te = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][k & 1])
+                        if host_mode:
+                            enc, te = ln["enc"].encode_host(h_in, ln["tol"], out=ln["data"][k & 1])
+                        else:
+                            ln["enc"].copy(ln["work"], orig, nelem * 8)
+                            enc, te = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][k & 1])
                         box[k & 1] = (enc, te)
                         coded[k & 1].release()
                 except Exception as exc:
@@ -255,15 +334,17 @@ def main():
                         if errors:
                             return
                         enc, te = box[k & 1]
-                        td = ln["dec"].decode(ln["rec"], shape, enc)
+                        td = ln["dec"].decode_host(ln["out"], enc) if host_mode else ln["dec"].decode(ln["rec"], shape, enc)
                         free[k & 1].release()
                         if record:
                             with lock:
-                                acc["fwd_ms"].append(te["transform_ms"]); acc["inv_ms"].append(td["transform_ms"])
-                                acc["quant_ms"].append(te["quant_ms"]); acc["dequant_ms"].append(td["quant_ms"])
-                                acc["enc_s"].append(te["total"]); acc["dec_s"].append(td["total"])
-                                acc["enc_rc_s"].append(te["rangecoder"]); acc["dec_rc_s"].append(td["rangecoder"])
-                                acc["enc_gpu_s"].append(te["gpu"]); acc["dec_gpu_s"].append(td["gpu"])
+                                for key, val in (("fwd_ms", te["transform_ms"]), ("inv_ms", td["transform_ms"]), ("quant_ms", te["quant_ms"]),
+                                                 ("dequant_ms", td["quant_ms"]), ("minmax_ms", te["minmax_ms"]), ("enc_s", te["total"]),
+                                                 ("dec_s", td["total"]), ("enc_rc_s", te["rangecoder"]), ("dec_rc_s", td["rangecoder"]),
+                                                 ("enc_gpu_s", te["gpu"]), ("dec_gpu_s", td["gpu"]), ("enc_wait_s", te["wait"]),
+                                                 ("dec_wait_s", td["wait"]), ("enc_h2d_ms", te["h2d_ms"]), ("enc_d2h_ms", te["d2h_ms"]),
+                                                 ("dec_h2d_ms", td["h2d_ms"]), ("dec_d2h_ms", td["d2h_ms"]), ("nlay", enc["nlay"])):
+                                    acc[key].append(val)
                                 stats[ln["tol"]] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"]}
                 except Exception as exc:
                     errors.append(exc)
@@ -290,8 +371,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # accuracy of the last reconstruction (tols[-1]) against the original, on the device
-    diff, amax = lanes[-1]["dec"].linf(orig, lanes[-1]["rec"], nelem)
+    # accuracy of the last reconstruction (tols[-1]) against the original
+    if host_mode:
+        diff = amax = 0.0
+        for z in range(0, n, 64):  # in slabs: no field-sized temporaries
+            a, b = h_in[z:z + 64], lanes[-1]["out"][z:z + 64]
+            diff = max(diff, float(np.abs(a - b).max()))
+            amax = max(amax, float(np.abs(a).max()))
+    else:
+        diff, amax = lanes[-1]["dec"].linf(orig, lanes[-1]["rec"], nelem)
     linf_rel = diff / amax
 
     mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
@@ -302,29 +390,58 @@ def main():
         fwd_ms, inv_ms = mean(acc["fwd_ms"]), mean(acc["inv_ms"])
         t_ms = 0.5 * (fwd_ms + inv_ms)
         achieved = alg_bytes / (t_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(n)
+
+        def group(alg, ms):  # roofline of a kernel group from its algorithmic bytes and its HIP-event time
+            gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"algorithmic_bytes": alg, "ms": round(ms, 3), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        L = mean(acc["nlay"])  # planes per field, mean over the batch
+        nbytes_field = nelem * 8.0
         out = {
-            "metric": "encode+decode MB/s per GPU on 1024^3 fp64 (field resident in HBM; host range coder included)",
+            "metric": "encode+decode MB/s on %d^3 fp64, %s (whole job = n_gpus x per-GPU rate; host range coder included)"
+                      % (n, "host buffer to host buffer" if host_mode else "field resident in HBM"),
             "value": round(total_mb / dt, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "single %d^3 fp64 field per GPU, tol=%s (%s)"
-                                   % (n, " and ".join("%g" % t for t in tols),
-                                      "BASELINE configs[2]" if n == 1024 else "BASELINE configs[1]/[3] shape" if n == 512 else "parity-size run"),
+            "per_gpu_MBps": round(total_mb / dt / world, 2),
+            "config": {"workload": "%s, tol=%s (%s)"
+                                   % ("single %d^3 fp64 field per GPU" % n if world == 1 else "%d independent %d^3 fp64 fields, one per GPU" % (world, n),
+                                      " and ".join("%g" % t for t in tols),
+                                      "BASELINE configs[2]" if n == 1024 else
+                                      ("BASELINE configs[3]: independent 512^3 fields sharded one per GPU" if world > 1 else "BASELINE configs[1]") if n == 512
+                                      else "parity-size run"),
+                       "boundary": "host buffers (pinned), wr_encode_host / wr_decode_host" if host_mode else "device buffers, wr_encode_device / wr_decode_device",
                        "field_shards": world, "range_coder_threads": {"encode": args.enc_threads or args.threads, "decode": args.threads},
                        "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": len(lanes), "sizing": limits, "pipeline": "encode(k+1) overlaps decode(k)",
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(n),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "3-D CDF-9/7 transform, 4 levels (mean of forward and inverse), all launches",
                          "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3)},
+            # the other kernel groups: algorithmic bytes per element 17 L - 8 (quantizer, L planes), L + 8
+            # (dequantise-accumulate), 8 per min/max pass (two passes per encode); times from HIP events in the run
+            "roofline_groups": {"forward_transform": group(alg_bytes, fwd_ms), "inverse_transform": group(alg_bytes, inv_ms),
+                                "quantizer": group((17.0 * L - 8.0) * nelem, mean(acc["quant_ms"])),
+                                "dequantizer": group((L + 8.0) * nelem, mean(acc["dequant_ms"])),
+                                "minmax_x2": group(2 * nbytes_field, mean(acc["minmax_ms"])), "mean_planes": round(L, 2)},
             "stages": {"encode_s": round(mean(acc["enc_s"]), 3), "decode_s": round(mean(acc["dec_s"]), 3),
                        "encode_gpu_s": round(mean(acc["enc_gpu_s"]), 4), "decode_gpu_s": round(mean(acc["dec_gpu_s"]), 4),
+                       "encode_slot_wait_s": round(mean(acc["enc_wait_s"]), 4), "decode_slot_wait_s": round(mean(acc["dec_wait_s"]), 4),
                        "encode_rangecoder_s": round(mean(acc["enc_rc_s"]), 3),
                        "decode_rangecoder_s": round(mean(acc["dec_rc_s"]), 3),
                        "quant_ms": round(mean(acc["quant_ms"]), 3), "dequant_ms": round(mean(acc["dequant_ms"]), 3),
+                       "minmax_ms": round(mean(acc["minmax_ms"]), 3),
+                       "pcie": {"encode_field_h2d_ms": round(mean(acc["enc_h2d_ms"]), 2), "encode_planes_d2h_span_ms": round(mean(acc["enc_d2h_ms"]), 2),
+                                "decode_planes_h2d_ms": round(mean(acc["dec_h2d_ms"]), 2), "decode_field_d2h_ms": round(mean(acc["dec_d2h_ms"]), 2),
+                                "field_h2d_GBps": round(nbytes_field / 1e6 / max(1e-9, mean(acc["enc_h2d_ms"])), 1) if host_mode else None,
+                                "field_d2h_GBps": round(nbytes_field / 1e6 / max(1e-9, mean(acc["dec_d2h_ms"])), 1) if host_mode else None},
                        "device_only_MBps": round(2 * field_mb / max(1e-9, mean(acc["enc_gpu_s"]) + mean(acc["dec_gpu_s"])), 1)},
             "accuracy": {"tol": tols[-1], "linf_rel": linf_rel},
         }
+        other, other_src = committed_extra("bench%d_resident.json" % n if host_mode else "bench%d_host.json" % n)
+        if other:
+            out["resident_fields" if host_mode else "host_buffers"] = {"value": other.get("value"), "unit": "MB/s", "source": other_src}
         try:  # peak resident host memory of this rank (pinned staging included)
             with open("/proc/self/status") as fh:
                 hwm = [l for l in fh if l.startswith("VmHWM")][0].split()
@@ -336,14 +453,19 @@ def main():
             # encoding_wrap / decoding_wrap caller sees (outside the timed region)
             api.set_threads(8)
             ln = lanes[-1]
-            ln["enc"].copy(ln["work"], orig, nelem * 8)
-            enc1, te1 = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][0])
-            td1 = ln["dec"].decode(ln["rec"], shape, enc1)
+            if host_mode:
+                enc1, te1 = ln["enc"].encode_host(h_in, ln["tol"], out=ln["data"][0])
+                td1 = ln["dec"].decode_host(ln["out"], enc1)
+            else:
+                ln["enc"].copy(ln["work"], orig, nelem * 8)
+                enc1, te1 = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][0])
+                td1 = ln["dec"].decode(ln["rec"], shape, enc1)
             out["single_field"] = {"tol": ln["tol"], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
                                    "decode_s": round(td1["total"], 3),
                                    "MBps": round(field_mb / (te1["total"] + td1["total"]), 1)}
             api.set_threads(args.threads, args.enc_threads)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols)
+            ncores = max(1, int(limits["cpus_per_rank"]))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols, ncores)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -17,6 +17,7 @@ int main(int argc, char** argv)
     const double tolrel = argc > 1 ? atof(argv[1]) : 1e-6;
     const size_t n = (size_t)nx * ny * nz;
     double* fld = malloc(n * sizeof(double));
+    double* work = malloc(n * sizeof(double)); /* encoding_wrap overwrites its input (reference README.md:197) */
     double* rec = malloc(n * sizeof(double));
     /* smooth field + a ripple, x fastest (idx = ix + nx*(iy + ny*iz)), cf. example_fort.f90:82-91 */
     for (int iz = 0; iz < nz; iz++)
@@ -35,7 +36,8 @@ int main(int argc, char** argv)
     setup_wr(nx, ny, nz, &nlaymax, &ntot_enc_max);
     unsigned char* data_enc = malloc(ntot_enc_max);
 
-    encoding_wrap(nx, ny, nz, fld, 1, 1, 1, 1, &cutoff, &tolabs, &midval, &halfspanval, &wlev, &nlay, &ntot_enc,
+    for (size_t j = 0; j < n; j++) work[j] = fld[j];
+    encoding_wrap(nx, ny, nz, work, 1, 1, 1, 1, &cutoff, &tolabs, &midval, &halfspanval, &wlev, &nlay, &ntot_enc,
                   deps_vec, minval_vec, len_enc_vec, data_enc);
     decoding_wrap(nx, ny, nz, rec, &tolabs, &midval, &halfspanval, &wlev, &nlay, &ntot_enc, deps_vec, minval_vec,
                   len_enc_vec, data_enc);
@@ -44,6 +46,6 @@ int main(int argc, char** argv)
     for (size_t j = 0; j < n; j++) linf = fmax(linf, fabs(rec[j] - fld[j]));
     printf("planes=%u coded=%lu bytes ratio=%.2f Linf_abs=%.3e Linf_rel=%.3e (tol %.1e)\n", (unsigned)nlay, ntot_enc,
            (double)(n * sizeof(double)) / (double)ntot_enc, linf, linf / fmax_abs, tolrel);
-    free(data_enc); free(rec); free(fld);
+    free(data_enc); free(rec); free(work); free(fld);
     return linf / fmax_abs <= 1.05 * tolrel ? 0 : 1;
 }

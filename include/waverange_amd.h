@@ -38,7 +38,10 @@ void setup_wr(int nx, int ny, int nz, unsigned char *nlaymax, unsigned long *nto
 /* replaces encoding_wrap, reference src/core/wrappers.cpp:228-452 (wrappers.h:53).
  * fld_1d: host double[nx*ny*nz], x fastest.  data_enc: host buffer of ntot_enc_max bytes.
  * mx*my*mz > 1 selects the reference's non-uniform (local) cutoff branch, wrappers.cpp:343-379.
- * Unlike the reference, fld_1d is left untouched unless WR_WRITEBACK_RESIDUAL=1 is set. */
+ * As in the reference (wrappers.cpp:397-398, README.md:197) fld_1d is overwritten with the residual
+ * in wavelet space; WR_WRITEBACK_RESIDUAL=0 or wr_set_writeback_residual(0) skips that download.
+ * Thread safety: like the reference, encoding_wrap / decoding_wrap / waveletcdf97_3d may be called
+ * concurrently from several threads on distinct buffers (every call borrows its own context). */
 void encoding_wrap(int nx, int ny, int nz, double *fld_1d, int wtflag, int mx, int my, int mz,
                    double *cutoffvec, double *tolabs, double *midval, double *halfspanval,
                    unsigned char *wlev, unsigned char *nlay, unsigned long *ntot_enc,
@@ -129,6 +132,10 @@ typedef struct wr_timings {
     float transform_ms; /* all launches of the forward or inverse transform */
     float quant_ms;     /* all quantizer-plane (or the dequantise-accumulate) launches */
     float minmax_ms;    /* stand-alone min/max reductions */
+    double wait;        /* waiting for a free work-space slot of the device */
+    float h2d_ms;       /* host entry points: upload of the field (encode) / the planes (decode) */
+    float d2h_ms;       /* first plane copy .. last copy of the call on the download stream (encode) /
+                           download of the field (decode) */
 } wr_timings;
 
 const char *wr_last_error(void);
@@ -142,9 +149,23 @@ void wr_set_threads(int nthreads);
 /* a different count for the encoder alone (0 = follow wr_set_threads, which also resets this): the
  * encoder interleaves 2 planes as efficiently as 3-4, the decoder is at its best with 4 per thread */
 void wr_set_encoder_threads(int nthreads);
+/* whether the drop-in encoding_wrap leaves the residual in fld_1d as the reference does (default 1,
+ * WR_WRITEBACK_RESIDUAL in the environment): callers that discard the array save a field download */
+void wr_set_writeback_residual(int on);
+/* Work-space slots of a device (1..4, default 3 or WR_SLOTS): how many device phases may be in
+ * flight at once -- one uploading, one in its kernels, one downloading.  A slot holds a staging
+ * field, the coefficient array and 8 plane buffers (3.1 x the field size) and is only populated
+ * when concurrent callers need it; if the device runs out of memory the library keeps to the
+ * slots it has. */
+int wr_set_device_slots(int device, int nslots);
+/* process-wide event counters (diagnostics and tests) */
+#define WR_STAT_EARLY_DECODES 0   /* decode calls that uploaded each plane as soon as it was decoded */
+#define WR_STAT_SLOTS_POPULATED 1 /* work-space slots that received device buffers */
+unsigned long wr_stat(int what);
 
-/* One context per (device, stream owner).  Work space (scratch field, plane buffers, pinned
- * staging) is grown on demand and kept.  stream == NULL makes the context create its own. */
+/* One context per concurrent caller: (device, kernel stream, pinned plane staging, coded-stream
+ * buffers), grown on demand and kept.  The device work space is shared between the contexts of a
+ * GPU (wr_set_device_slots).  stream == NULL makes the context create its own. */
 int wr_ctx_create(wr_ctx **ctx, int device, void *hip_stream);
 void wr_ctx_destroy(wr_ctx *ctx);
 int wr_ctx_sync(wr_ctx *ctx);
@@ -158,7 +179,12 @@ int wr_dev_free(wr_ctx *ctx, void *ptr);
 int wr_dev_upload(wr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int wr_dev_download(wr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
-int wr_dev_copy(wr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* async, ctx stream */
+/* pinned host memory: field and coded-stream buffers allocated here move over PCIe by DMA without
+ * a staging copy (pageable buffers work everywhere too, at roughly half the rate) */
+int wr_host_alloc(void **ptr, size_t bytes);
+int wr_host_free(void *ptr);
+
+int wr_dev_copy(wr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* ctx stream, waits */
 /* max|a-b| and max|a| over n doubles (accuracy check of a reconstruction, "L-inf vs tol") */
 int wr_dev_linf(wr_ctx *ctx, const double *d_a, const double *d_b, size_t n, double *max_abs_diff,
                 double *max_abs_a);
@@ -197,8 +223,24 @@ int wr_encode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtf
 int wr_encode_device_local(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtflag, int mx,
                            int my, int mz, const double *cutoffvec, wr_enc_info *info,
                            unsigned char *data_enc, size_t cap, wr_timings *tm);
+/* data_len: bytes readable at data_enc (0 = trust info->ntot_enc, as the reference does) */
 int wr_decode_device(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz,
-                     const wr_enc_info *info, const unsigned char *data_enc, wr_timings *tm);
+                     const wr_enc_info *info, const unsigned char *data_enc, size_t data_len,
+                     wr_timings *tm);
+
+/* --- whole hot path host buffer to host buffer: what encoding_wrap / decoding_wrap run on, with an
+ * explicit context (one per concurrent caller), error codes and timings.  The field is staged through
+ * the device's work-space slot: upload on the device's upload stream, kernels, planes / field back on
+ * the download stream, so that concurrent calls overlap their copies with one another's kernels and
+ * host range coding.  h_fld may be pinned (wr_host_alloc) or pageable.  Encode leaves h_fld untouched
+ * unless wr_ctx_set_keep_residual(ctx, 1) asks for the reference's residual write-back. */
+int wr_encode_host(wr_ctx *ctx, double *h_fld, int nx, int ny, int nz, int wtflag, int mx, int my,
+                   int mz, const double *cutoffvec, wr_enc_info *info, unsigned char *data_enc,
+                   size_t cap, wr_timings *tm);
+int wr_decode_host(wr_ctx *ctx, double *h_fld, int nx, int ny, int nz, const wr_enc_info *info,
+                   const unsigned char *data_enc, size_t data_len, wr_timings *tm);
+/* waveletcdf97_3d on a host array, in place */
+int wr_transform_host(wr_ctx *ctx, double *h_fld, int nx, int ny, int nz, int lvl);
 
 /* --- host range coder alone (one plane stream), rows a6/a7/a10 of SURVEY.md 8a */
 size_t wr_range_encode_bound(size_t n);

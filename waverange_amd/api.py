@@ -53,7 +53,7 @@ class EncInfo(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("total", C.c_double), ("gpu", C.c_double), ("transfer", C.c_double),
                 ("rangecoder", C.c_double), ("transform_ms", C.c_float), ("quant_ms", C.c_float),
-                ("minmax_ms", C.c_float)]
+                ("minmax_ms", C.c_float), ("wait", C.c_double), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -101,8 +101,19 @@ def lib():
                                    C.POINTER(EncInfo), _vp, C.c_size_t, C.POINTER(Timings)]
     L.wr_encode_device_local.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
                                          C.POINTER(EncInfo), _vp, C.c_size_t, C.POINTER(Timings)]
-    L.wr_decode_device.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(EncInfo), _vp,
+    L.wr_decode_device.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(EncInfo), _vp, C.c_size_t,
                                    C.POINTER(Timings)]
+    L.wr_encode_host.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                                 C.POINTER(EncInfo), _vp, C.c_size_t, C.POINTER(Timings)]
+    L.wr_decode_host.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(EncInfo), _vp, C.c_size_t,
+                                 C.POINTER(Timings)]
+    L.wr_transform_host.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.wr_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    L.wr_host_free.argtypes = [_vp]
+    L.wr_set_device_slots.argtypes = [C.c_int, C.c_int]
+    L.wr_set_writeback_residual.argtypes = [C.c_int]
+    L.wr_stat.restype = C.c_ulong
+    L.wr_stat.argtypes = [C.c_int]
     L.wr_range_encode_bound.restype = C.c_size_t
     L.wr_range_encode_bound.argtypes = [C.c_size_t]
     L.wr_range_encode.restype = C.c_size_t
@@ -141,6 +152,44 @@ def set_threads(n, encoder=0):
     """coder threads per call; `encoder` > 0 gives the encoder its own count"""
     lib().wr_set_threads(int(n))
     lib().wr_set_encoder_threads(int(encoder))
+
+
+def set_device_slots(device, nslots):
+    _check(lib().wr_set_device_slots(int(device), int(nslots)))
+
+
+STAT_EARLY_DECODES, STAT_SLOTS_POPULATED = 0, 1
+
+
+def stat(what):
+    return lib().wr_stat(int(what))
+
+
+def set_writeback_residual(on):
+    lib().wr_set_writeback_residual(int(on))
+
+
+class _Pinned:
+    def __init__(self, nbytes):
+        p = _vp()
+        _check(lib().wr_host_alloc(C.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        if self.ptr and _lib is not None:
+            _lib.wr_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_array(shape, dtype=np.float64):
+    """numpy array on pinned host memory (wr_host_alloc): moves over PCIe by DMA without a staging copy.
+    The memory is released when the last view of the array is gone."""
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    owner = _Pinned(max(16, count * dt.itemsize))
+    buf = (C.c_ubyte * owner.nbytes).from_address(owner.ptr)
+    buf._owner = owner  # keeps the allocation alive as long as the ctypes buffer (numpy's base)
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 
 # ---------------------------------------------------------------------------------------
@@ -211,7 +260,7 @@ def encoding_wrap(fld, tolrel, wtflag=1):
     L = nlay.value
     return dict(tolabs=tolabs.value, midval=midval.value, halfspanval=halfspan.value, wlev=wlev.value,
                 nlay=L, ntot_enc=ntot_enc.value, deps_vec=deps[:L].copy(), minval_vec=mins[:L].copy(),
-                len_enc_vec=[int(v) for v in lens[:L]], data=data[:ntot_enc.value].copy())
+                len_enc_vec=[int(v) for v in lens[:L]], data=data[:ntot_enc.value].copy(), residual=work)
 
 
 def decoding_wrap(enc, shape):
@@ -376,8 +425,42 @@ class Context:
         data = np.ascontiguousarray(enc["data"], dtype=np.uint8)
         if data.size == 0:
             data = np.zeros(1, dtype=np.uint8)
-        _check(lib().wr_decode_device(self.h, buf.ptr, nx, ny, nz, C.byref(info), data.ctypes.data, C.byref(tm)))
+        _check(lib().wr_decode_device(self.h, buf.ptr, nx, ny, nz, C.byref(info), data.ctypes.data, data.size,
+                                      C.byref(tm)))
         return tm.as_dict()
+
+    # ---- host buffer to host buffer (what encoding_wrap / decoding_wrap run on)
+    def encode_host(self, fld, tolrel, wtflag=1, out=None, cutoff=None, m=(1, 1, 1)):
+        """fld: C-contiguous float64 array shaped (nz, ny, nx), pinned (pinned_array) or pageable; left
+        untouched unless set_keep_residual(True).  Returns (info dict incl. data, timings)."""
+        assert fld.dtype == np.float64 and fld.flags["C_CONTIGUOUS"]
+        nz, ny, nx = fld.shape
+        _, cap = setup_wr(nx, ny, nz)
+        data = out if out is not None else np.empty(cap, dtype=np.uint8)
+        cut = np.ascontiguousarray([tolrel] if cutoff is None else cutoff, dtype=np.float64)
+        info, tm = EncInfo(), Timings()
+        _check(lib().wr_encode_host(self.h, fld.ctypes.data, nx, ny, nz, wtflag, m[0], m[1], m[2],
+                                    cut.ctypes.data_as(_dp), C.byref(info), data.ctypes.data, data.size, C.byref(tm)))
+        d = info.as_dict()
+        d["data"] = data[:info.ntot_enc]
+        return d, tm.as_dict()
+
+    def decode_host(self, out, enc):
+        """out: C-contiguous float64 array shaped (nz, ny, nx) that receives the reconstruction."""
+        assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+        nz, ny, nx = out.shape
+        info = EncInfo.from_dict(enc)
+        tm = Timings()
+        data = np.ascontiguousarray(enc["data"], dtype=np.uint8)
+        if data.size == 0:
+            data = np.zeros(1, dtype=np.uint8)
+        _check(lib().wr_decode_host(self.h, out.ctypes.data, nx, ny, nz, C.byref(info), data.ctypes.data, data.size,
+                                    C.byref(tm)))
+        return tm.as_dict()
+
+    def transform_host(self, fld, lvl):
+        nz, ny, nx = fld.shape
+        _check(lib().wr_transform_host(self.h, fld.ctypes.data, nx, ny, nz, lvl))
 
     def bench_transform(self, buf, shape, lvl, reps=1):
         nz, ny, nx = shape

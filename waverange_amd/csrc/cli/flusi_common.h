@@ -62,12 +62,11 @@ inline bool get_params(int argc, char** argv, bool use_inmeta, const char* const
     return true;
 }
 
-// Two contexts on one GPU: while dataset k is in its host range-coding phase on one context, the
-// device phase of dataset k+1 runs on the other (device phases are serialised inside the library).
+// Two contexts on one GPU: while dataset k is in its host range-coding phase on one context, dataset
+// k+1 is uploaded and transformed through the other (wr_encode_host / wr_decode_host: the library
+// overlaps the copies of one call with the kernels and the host coding of the other).
 struct Pipeline {
     wr_ctx* ctx[2] = {nullptr, nullptr};
-    void* dbuf[2] = {nullptr, nullptr};
-    size_t cap[2] = {0, 0};
     bool open()
     {
         int dev = 0;
@@ -76,21 +75,10 @@ struct Pipeline {
             if (wr_ctx_create(&ctx[i], dev, nullptr) != WR_OK) { std::cerr << "wrenc/wrdec: " << wr_last_error() << std::endl; return false; }
         return true;
     }
-    double* field(int slot, size_t n)
-    {
-        if (cap[slot] < n) {
-            if (dbuf[slot]) wr_dev_free(ctx[slot], dbuf[slot]);
-            if (wr_dev_alloc(ctx[slot], &dbuf[slot], n * sizeof(double)) != WR_OK) return nullptr;
-            cap[slot] = n;
-        }
-        return static_cast<double*>(dbuf[slot]);
-    }
     ~Pipeline()
     {
-        for (int i = 0; i < 2; i++) {
-            if (ctx[i] && dbuf[i]) wr_dev_free(ctx[i], dbuf[i]);
+        for (int i = 0; i < 2; i++)
             if (ctx[i]) wr_ctx_destroy(ctx[i]);
-        }
     }
 };
 

@@ -98,15 +98,13 @@ int main(int argc, char** argv)
         const size_t n = (size_t)it.nx * it.ny * it.nz;
         const int slot = (int)(k & 1);
         if (k >= 2) finish(items[k - 2]);
-        double* d_fld = pipe.field(slot, n);
-        if (!d_fld) { std::cerr << "wrdec: " << wr_last_error() << endl; return 1; }
         it.rec.resize(n);
         wr_ctx* c = pipe.ctx[slot];
         Item* ip = &it;
-        it.done = std::async(std::launch::async, [c, d_fld, ip, n]() {
-            if (int rc = wr_decode_device(c, d_fld, ip->nx, ip->ny, ip->nz, &ip->info, ip->data.data(), nullptr)) return rc;
+        it.done = std::async(std::launch::async, [c, ip]() {
+            const int rc = wr_decode_host(c, ip->rec.data(), ip->nx, ip->ny, ip->nz, &ip->info, ip->data.data(), ip->data.size(), nullptr);
             std::vector<unsigned char>().swap(ip->data);
-            return wr_dev_download(c, ip->rec.data(), d_fld, n * sizeof(double));
+            return rc;
         });
     }
     for (size_t k = items.size() >= 2 ? items.size() - 2 : 0; k < items.size(); k++) finish(items[k]);

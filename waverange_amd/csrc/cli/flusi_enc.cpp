@@ -108,14 +108,14 @@ int main(int argc, char** argv)
         unsigned char nl; unsigned long cap;
         setup_wr(it.nx, it.ny, it.nz, &nl, &cap);
         it.data.resize(cap);
-        double* d_fld = pipe.field(slot, n);
-        if (!d_fld) { std::cerr << "wrenc: " << wr_last_error() << endl; return 1; }
         wr_ctx* c = pipe.ctx[slot];
         Item* ip = &it;
-        it.done = std::async(std::launch::async, [c, d_fld, ip, n, tol]() {
-            if (int rc = wr_dev_upload(c, d_fld, ip->fld.data(), n * sizeof(double))) return rc;
+        it.done = std::async(std::launch::async, [c, ip, tol]() {
+            const double cutoff = tol;
+            const int rc = wr_encode_host(c, ip->fld.data(), ip->nx, ip->ny, ip->nz, 1, 1, 1, 1, &cutoff, &ip->info, ip->data.data(),
+                                          ip->data.size(), nullptr);
             std::vector<double>().swap(ip->fld);
-            return wr_encode_device(c, d_fld, ip->nx, ip->ny, ip->nz, 1, tol, &ip->info, ip->data.data(), ip->data.size(), nullptr);
+            return rc;
         });
     }
     for (size_t k = items.size() >= 2 ? items.size() - 2 : 0; k < items.size(); k++) finish(items[k]);

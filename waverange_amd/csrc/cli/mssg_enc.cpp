@@ -271,6 +271,7 @@ int restart_set(const Params& p, int nbytes)
 
 int main(int argc, char** argv)
 {
+    setenv("WR_WRITEBACK_RESIDUAL", "0", 0);  // the residual encoding_wrap leaves in the field array is not used here
     Params p;
     if (!get_params(argc, argv, &p)) return -1;
     const int nbytes = p.intype == 1 ? 4 : 8;

@@ -2,8 +2,11 @@
 //
 // Same command line, prompts and output files as the reference's generic decoder
 // (src/generic/gen_dec.cpp):   wrdec ENCODED_FILE HEADER_FILE EXTRACTED_FILE TYPE ENDIANFLIP
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -57,10 +60,41 @@ int main(int argc, char** argv)
     std::ifstream finput(in_name, std::ios::binary | std::ios::in);
     if (!finput.is_open()) { cout << "Cannot open " << in_name << endl; return 1; }
 
-    std::vector<double> fld;
-    std::vector<unsigned char> data_enc;
-    for (int it = 0; it < nf; it++) {
+    // Field pipeline, as in wrenc: while field k is inside decoding_wrap on a worker thread, the main thread
+    // reads field k+1's header record and coded bytes and writes field k-1 to the output file, in field
+    // order (WR_CLI_PIPELINE fields in flight, default 2; 0 = strictly one after the other).
+    int depth = 2;
+    if (const char* e = getenv("WR_CLI_PIPELINE")) depth = atoi(e);
+    if (depth > nf - 1) depth = nf - 1;
+    if (depth < 0) depth = 0;
+    if (depth > 0) setenv("WR_QUIET", "1", 0);
+    struct Item {
         wrio::FieldHeader h;
+        std::vector<double> fld;
+        std::vector<unsigned char> data_enc;
+        std::future<void> done;
+        bool decoded = false;
+    };
+    std::vector<Item> items(nf);
+    auto finish = [&](int it) {
+        Item& im = items[it];
+        const wrio::FieldSpec& s = im.h.spec;
+        const size_t ntot = s.count();
+        if (im.decoded) {
+            im.done.get();
+            cout << "  decode: fld_1d_rec[0]=" << im.fld[0] << " fld_1d_rec[last]=" << im.fld[ntot - 1] << endl;
+        }
+        double lo = im.fld[0], hi = im.fld[0];
+        for (size_t j = 0; j < ntot; j++) { lo = fmin(lo, im.fld[j]); hi = fmax(hi, im.fld[j]); }
+        cout << "        min=" << lo << " max=" << hi << endl;
+        wrio::write_field(out_name, it == 0, file_type, flip != 0, s, im.h.recl, im.fld.data());
+        cout << "  wrote: fld_1d_rec[0]=" << im.fld[0] << " fld_1d_rec[last]=" << im.fld[ntot - 1] << endl;
+        std::vector<double>().swap(im.fld);
+        std::vector<unsigned char>().swap(im.data_enc);
+    };
+    for (int it = 0; it < nf; it++) {
+        Item& im = items[it];
+        wrio::FieldHeader& h = im.h;
         wrio::read_field_header(fheader, it, h);
         const wrio::FieldSpec& s = h.spec;
         // echo of the header values, gen_aux.cpp:626-643
@@ -76,28 +110,36 @@ int main(int argc, char** argv)
         cout << "  nx=" << s.nx << "  ny=" << s.ny << "  nz=" << s.nz << "  nh=" << s.nh;
         if (s.idinv) cout << " and reordering" << endl; else cout << endl;
         const size_t ntot = s.count();
-        fld.assign(ntot, 0.0);
+        im.fld.assign(ntot, 0.0);
         if (s.icomp) {
-            for (size_t j = 0; j < ntot; j++) fld[j] = h.midval;  // gen_dec.cpp:201
+            for (size_t j = 0; j < ntot; j++) im.fld[j] = h.midval;  // gen_dec.cpp:201
             if (h.ntot_enc > 0) {
-                data_enc.resize(h.ntot_enc);
-                finput.read(reinterpret_cast<char*>(data_enc.data()), (std::streamsize)h.ntot_enc);
+                im.data_enc.resize(h.ntot_enc);
+                finput.read(reinterpret_cast<char*>(im.data_enc.data()), (std::streamsize)h.ntot_enc);
                 if (finput.fail()) { cout << "Cannot read from " << in_name << endl; return 1; }
-                cout << "  decoding fld_1d_rec, field number " << it << endl;
-                unsigned char wlev = (unsigned char)h.wlev, nlay = (unsigned char)h.nlay;
-                decoding_wrap(s.nx, s.ny, s.nz * s.nh, fld.data(), &h.tolabs, &h.midval, &h.halfspanval, &wlev, &nlay,
-                              &h.ntot_enc, h.deps_vec, h.minval_vec, h.len_enc_vec, data_enc.data());
-                cout << "  decode: fld_1d_rec[0]=" << fld[0] << " fld_1d_rec[last]=" << fld[ntot - 1] << endl;
             }
         } else {
-            wrio::read_raw_field(finput, s.nbytes, fld.data(), ntot);
+            wrio::read_raw_field(finput, s.nbytes, im.fld.data(), ntot);
         }
-        double lo = fld[0], hi = fld[0];
-        for (size_t j = 0; j < ntot; j++) { lo = fmin(lo, fld[j]); hi = fmax(hi, fld[j]); }
-        cout << "        min=" << lo << " max=" << hi << endl;
-        wrio::write_field(out_name, it == 0, file_type, flip != 0, s, h.recl, fld.data());
-        cout << "  wrote: fld_1d_rec[0]=" << fld[0] << " fld_1d_rec[last]=" << fld[ntot - 1] << endl;
+        if (depth > 0 && it - depth >= 0) finish(it - depth);
+        if (s.icomp && h.ntot_enc > 0) {
+            cout << "  decoding fld_1d_rec, field number " << it << endl;
+            im.decoded = true;
+            Item* ip = &im;
+            auto work = [ip]() {
+                wrio::FieldHeader& hh = ip->h;
+                const wrio::FieldSpec& sp = hh.spec;
+                unsigned char wlev = (unsigned char)hh.wlev, nlay = (unsigned char)hh.nlay;
+                decoding_wrap(sp.nx, sp.ny, sp.nz * sp.nh, ip->fld.data(), &hh.tolabs, &hh.midval, &hh.halfspanval, &wlev, &nlay,
+                              &hh.ntot_enc, hh.deps_vec, hh.minval_vec, hh.len_enc_vec, ip->data_enc.data());
+            };
+            if (depth > 0) im.done = std::async(std::launch::async, work);
+            else { work(); std::promise<void> p; p.set_value(); im.done = p.get_future(); }
+        }
+        if (depth == 0) finish(it);
     }
+    if (depth > 0)
+        for (int it = std::max(0, nf - depth); it < nf; it++) finish(it);
     cout << "=== End of decompression ===\n";
     return 0;
 }

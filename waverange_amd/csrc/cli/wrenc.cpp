@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -249,48 +251,87 @@ int main(int argc, char** argv)
     { std::ofstream trunc(job.out_name, std::ios::binary | std::ios::out | std::ios::trunc); }
     if (job.file_type < 0 || job.file_type > 2) { cout << "Error: unknown file type" << endl; return 0; }
 
-    double cutoff = job.effective_tol;  // quirk Q1: one cutoff for all fields
+    // Field pipeline: while field k is inside encoding_wrap on a worker thread (upload, GPU kernels, host
+    // range coder), the main thread reads field k+1 from the input file and writes field k-1's header
+    // record and coded bytes, always in field order.  `depth` fields are in flight (WR_CLI_PIPELINE,
+    // default 2: the library overlaps the device stages of one with the host coding of the other; 0 =
+    // strictly one after the other with the reference's order of log lines).
+    int depth = 2;
+    if (const char* e = getenv("WR_CLI_PIPELINE")) depth = atoi(e);
+    if (depth > job.nf - 1) depth = job.nf - 1;
+    if (depth < 0) depth = 0;
+    if (depth > 0) setenv("WR_QUIET", "1", 0);  // the library's progress lines of concurrent fields would interleave
+    setenv("WR_WRITEBACK_RESIDUAL", "0", 0);    // the residual encoding_wrap leaves in the field array is not used here
+
+    const double cutoff = job.effective_tol;  // quirk Q1: one cutoff for all fields
     long pos = 0;
-    unsigned char recl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long prev_ntot_enc = 0;  // quirk Q2: stale value reused for uncompressed fields
-    std::vector<double> fld;
-    std::vector<unsigned char> data_enc;
+    struct Item {
+        wrio::FieldHeader h;
+        std::vector<double> fld;
+        std::vector<unsigned char> data_enc;
+        std::future<void> done;
+    };
+    std::vector<Item> items(job.nf);
+    auto finish = [&](int it) {  // in field order: wait for the codec, then append to .wrh / .wrb
+        Item& im = items[it];
+        const wrio::FieldSpec& s = im.h.spec;
+        if (s.icomp) {
+            im.done.get();
+            cout << "        tolabs=" << im.h.tolabs << endl;
+            wrio::append_field_header(job.header_name, it, im.h, im.h.ntot_enc);
+            if (im.h.ntot_enc > 0) wrio::append_bytes(job.out_name, im.data_enc.data(), im.h.ntot_enc);
+            prev_ntot_enc = im.h.ntot_enc;
+        } else {
+            wrio::append_field_header(job.header_name, it, im.h, prev_ntot_enc);
+            wrio::append_raw_field(job.out_name, s.nbytes, im.fld.data(), s.count());
+        }
+        std::vector<double>().swap(im.fld);
+        std::vector<unsigned char>().swap(im.data_enc);
+    };
+    unsigned char recl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < job.nf; it++) {
+        Item& im = items[it];
         const wrio::FieldSpec& s = job.fields[it];
         cout << "Field number " << it << endl;
         cout << "  contains " << s.nbytes << "-byte floating point data" << endl;
         cout << "  nx=" << s.nx << "  ny=" << s.ny << "  nz=" << s.nz << "  nh=" << s.nh;
         if (s.idinv) cout << " and reordering" << endl; else cout << endl;
         const size_t ntot = s.count();
-        wrio::read_field(job.in_name, job.file_type, job.flip != 0, s, recl, &pos, fld);
-        cout << "  read: fld_1d[0]=" << fld[0] << " fld_1d[last]=" << fld[ntot - 1] << endl;
-        double lo = fld[0], hi = fld[0];
-        for (size_t j = 0; j < ntot; j++) { lo = fmin(lo, fld[j]); hi = fmax(hi, fld[j]); }
+        wrio::read_field(job.in_name, job.file_type, job.flip != 0, s, recl, &pos, im.fld);
+        cout << "  read: fld_1d[0]=" << im.fld[0] << " fld_1d[last]=" << im.fld[ntot - 1] << endl;
+        double lo = im.fld[0], hi = im.fld[0];
+        for (size_t j = 0; j < ntot; j++) { lo = fmin(lo, im.fld[j]); hi = fmax(hi, im.fld[j]); }
         cout << "        min=" << lo << " max=" << hi << endl;
 
-        wrio::FieldHeader h;
-        h.spec = s;
-        for (int j = 0; j < 8; j++) h.recl[j] = recl[j];
+        im.h.spec = s;
+        for (int j = 0; j < 8; j++) im.h.recl[j] = recl[j];
+        if (depth > 0 && it - depth >= 0) finish(it - depth);  // `depth` fields in flight once this one is launched
         if (s.icomp) {
             cout << "  Compression enabled with base relative tolerance " << s.tol_base << endl;
             unsigned char nlaymax; unsigned long cap;
             setup_wr(s.nx, s.ny, s.nz * s.nh, &nlaymax, &cap);
-            if (data_enc.size() < cap) data_enc.resize(cap);
-            unsigned char wlev = 0, nlay = 0;
-            // nh > 1 folds into z (gen_enc.cpp:559,596)
-            encoding_wrap(s.nx, s.ny, s.nz * s.nh, fld.data(), 1, 1, 1, 1, &cutoff, &h.tolabs, &h.midval, &h.halfspanval,
-                          &wlev, &nlay, &h.ntot_enc, h.deps_vec, h.minval_vec, h.len_enc_vec, data_enc.data());
-            h.wlev = wlev; h.nlay = nlay;
-            cout << "        tolabs=" << h.tolabs << endl;
-            wrio::append_field_header(job.header_name, it, h, h.ntot_enc);
-            if (h.ntot_enc > 0) wrio::append_bytes(job.out_name, data_enc.data(), h.ntot_enc);
-            prev_ntot_enc = h.ntot_enc;
+            im.data_enc.resize(cap);
+            Item* ip = &im;
+            auto work = [ip, cutoff]() {
+                const wrio::FieldSpec& sp = ip->h.spec;
+                unsigned char wlev = 0, nlay = 0;
+                double cut = cutoff;
+                // nh > 1 folds into z (gen_enc.cpp:559,596)
+                encoding_wrap(sp.nx, sp.ny, sp.nz * sp.nh, ip->fld.data(), 1, 1, 1, 1, &cut, &ip->h.tolabs, &ip->h.midval,
+                              &ip->h.halfspanval, &wlev, &nlay, &ip->h.ntot_enc, ip->h.deps_vec, ip->h.minval_vec,
+                              ip->h.len_enc_vec, ip->data_enc.data());
+                ip->h.wlev = wlev; ip->h.nlay = nlay;
+            };
+            if (depth > 0) im.done = std::async(std::launch::async, work);
+            else { work(); std::promise<void> p; p.set_value(); im.done = p.get_future(); }
         } else {
             cout << "  Compression disabled" << endl;
-            wrio::append_field_header(job.header_name, it, h, prev_ntot_enc);
-            wrio::append_raw_field(job.out_name, s.nbytes, fld.data(), ntot);
         }
+        if (depth == 0) finish(it);
     }
+    if (depth > 0)
+        for (int it = std::max(0, job.nf - depth); it < job.nf; it++) finish(it);
     cout << "=== End of compression ===\n";
     return 0;
 }

@@ -3,19 +3,26 @@
 // Mirrors the reference's codec layer (src/core/wrappers.cpp) for the path
 //   encoding_wrap : min/max -> forward transform -> bit-plane quantizer loop -> range coder
 //   decoding_wrap : range decoder -> dequantise-accumulate -> inverse transform
-// with the field resident in HBM, the quantized planes streamed to pinned host memory on a
-// copy stream, and host range-coder threads (one per plane, or fewer with the planes of a field
-// interleaved in one loop: wr_set_threads).  Compiled with hipcc, strict IEEE
-// (-ffp-contract=off): the scalar arithmetic on deps/aopt/bopt/tolabs below must round
-// exactly as wrappers.cpp:292-340 does.
+// A call moves through three device stages, each with its own lock and (for the copies) its own
+// per-device stream, on one of a few work-space SLOTS per GPU:
+//   up      host -> device   field (encode) or quantized planes (decode)       stream DevPool::up
+//   kernels min/max, transform, quantizer / dequantizer                         the context's stream
+//   down    device -> host   planes + block histograms (encode) or field       stream DevPool::down
+// so that field k+1's upload and transform run under field k's plane download, and the host range
+// coder (one thread per plane, or fewer with the planes of a field interleaved in one loop:
+// wr_set_threads) starts on plane l the moment it is on the host.  Compiled with hipcc, strict IEEE
+// (-ffp-contract=off): the scalar arithmetic on deps/aopt/bopt/tolabs below must round exactly as
+// wrappers.cpp:292-340 does.
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -37,32 +44,45 @@ constexpr double kWavAccCoef = 1.75;
 constexpr unsigned long kSafetyBufferFactor = 1;
 
 thread_local std::string g_err;
-// Device phases of the contexts on one GPU are serialised by the lock of that GPU's shared work space
-// (DevPool below; they are tens of milliseconds); what overlaps between concurrent encode/decode calls
-// is the host range coding.
-int g_verbose = -1;  // -1: not initialised from the environment yet
-int g_threads = -1;  // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
-
-int g_enc_threads = 0;  // 0: same as g_threads (wr_set_encoder_threads)
+std::atomic<int> g_verbose{-1};      // -1: not initialised from the environment yet
+std::atomic<int> g_threads{-1};      // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
+std::atomic<int> g_enc_threads{0};   // 0: same as g_threads (wr_set_encoder_threads)
+std::atomic<unsigned long> g_stat[4];  // see wr_stat()
+std::atomic<int> g_writeback{-1};    // drop-in encoding_wrap leaves the residual in fld_1d (-1: from WR_WRITEBACK_RESIDUAL, default 1)
 
 int coder_threads()
 {
-    if (g_threads < 0) {
+    int t = g_threads.load();
+    if (t < 0) {
         const char* e = getenv("WR_THREADS");
         const int k = e ? atoi(e) : 0;
-        g_threads = k >= 1 ? k : WR_NLAYMAX;
+        t = k >= 1 ? k : WR_NLAYMAX;
+        g_threads.store(t);
     }
-    return g_threads;
+    return t;
 }
-int encoder_threads() { return g_enc_threads > 0 ? g_enc_threads : coder_threads(); }
+int encoder_threads() { const int e = g_enc_threads.load(); return e > 0 ? e : coder_threads(); }
 
 int verbose()
 {
-    if (g_verbose < 0) {
+    int v = g_verbose.load();
+    if (v < 0) {
         const char* q = getenv("WR_QUIET");
-        g_verbose = (q && *q && *q != '0') ? 0 : 1;
+        v = (q && *q && *q != '0') ? 0 : 1;
+        g_verbose.store(v);
     }
-    return g_verbose;
+    return v;
+}
+
+int writeback_residual()
+{
+    int v = g_writeback.load();
+    if (v < 0) {
+        const char* e = getenv("WR_WRITEBACK_RESIDUAL");
+        v = (e && *e) ? (atoi(e) ? 1 : 0) : 1;
+        g_writeback.store(v);
+    }
+    return v;
 }
 
 int fail(int code, const std::string& msg)
@@ -83,28 +103,48 @@ double now()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// One set of device work space.  A device phase owns a slot from its first copy to its last; the
+// kernels of different slots serialise on DevPool::cu_mu, their copies run under one another.
+struct Slot {
+    bool busy = false;
+    bool disabled = false;  // the device had no memory left for it: never handed out again
+    double* field = nullptr; size_t field_elems = 0;      // staging of a host caller's field
+    double* scratch = nullptr; size_t scratch_elems = 0;  // coefficient array (out-of-place fused transform)
+    double* lowbuf = nullptr; size_t lowbuf_elems = 0;    // compact low-pass boxes (fused transform)
+    uint8_t* planes = nullptr; size_t planes_bytes = 0;   // quantized planes
+    uint16_t* hist = nullptr; size_t hist_elems = 0;      // per-block byte histograms, all planes
+    bool allocated() const { return field || scratch || lowbuf || planes || hist; }
+    void release_buffers()
+    {
+        (void)hipFree(field); (void)hipFree(scratch); (void)hipFree(lowbuf); (void)hipFree(planes); (void)hipFree(hist);
+        field = scratch = lowbuf = nullptr; planes = nullptr; hist = nullptr;
+        field_elems = scratch_elems = lowbuf_elems = planes_bytes = hist_elems = 0;
+    }
+};
+
+constexpr int kMaxSlots = 4;
+
 }  // namespace
 
-// Device work space of the transform / quantizer phase, one per GPU and shared by all contexts on
-// it: a device phase holds `phase` from its first kernel to its last copy (phases of different
-// contexts would only fight over HBM bandwidth), so nothing in here is live outside the lock and
-// 1024^3 jobs cost 2 x 8.6 GB of HBM each (field in, field out) instead of 5 x.
+// Per-GPU state shared by all contexts on it: the work-space slots (a 1024^3 slot is 8.6 GB each for
+// field staging, coefficients and planes, 1.2 GB of low-pass boxes; slots are populated on demand, so a
+// lone caller uses one), one copy stream per direction (copies of all contexts queue on them in call
+// order and stay off the streams that run kernels) and the stage locks.
 struct DevPool {
-    std::mutex phase;
+    std::mutex mu; std::condition_variable cv;  // slot hand-out
+    Slot slots[kMaxSlots];
+    int max_slots = 3;
     int users = 0;
-    double* scratch = nullptr; size_t scratch_elems = 0;  // coefficient array (out-of-place fused transform)
-    uint8_t* planes = nullptr; size_t planes_bytes = 0;   // quantized planes
-    double* lowbuf = nullptr; size_t lowbuf_elems = 0;    // compact low-pass boxes (fused transform)
-    uint16_t* hist = nullptr; size_t hist_elems = 0;      // per-block byte histograms, all planes
+    hipStream_t up = nullptr, down = nullptr;
+    std::mutex up_mu, cu_mu, down_mu;
 };
 
 struct wr_ctx {
     int device = 0;
     DevPool* pool = nullptr;
-    hipStream_t stream = nullptr, copy = nullptr;
+    hipStream_t stream = nullptr;
     bool own_stream = false;
     bool keep_residual = false;
-    double* d_field = nullptr; size_t field_elems = 0;  // staging for the host-pointer API
     double* d_cutoff = nullptr; size_t cutoff_elems = 0;  // local cutoff vector (mx*my*mz > 1 only)
     double* d_partial = nullptr; double* d_result = nullptr;
     unsigned long long* d_idx = nullptr;
@@ -115,7 +155,9 @@ struct wr_ctx {
     uint16_t* h_hist = nullptr; size_t h_hist_elems = 0;  // pinned: per-block byte histograms, all planes
     // host coded-stream staging, one per plane
     uint8_t* enc_buf[WR_NLAYMAX] = {nullptr}; size_t enc_buf_bytes[WR_NLAYMAX] = {0};  // malloc'd: only coded bytes get touched
-    hipEvent_t ev_plane[WR_NLAYMAX], ev_copy[WR_NLAYMAX], ev_a, ev_b, ev_c, ev_d;
+    hipEvent_t ev_plane[WR_NLAYMAX] = {nullptr}, ev_copy[WR_NLAYMAX] = {nullptr};
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_mm = nullptr;
+    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     std::mutex mu;
 };
 
@@ -127,30 +169,100 @@ constexpr int kMaxDevices = 64;
 DevPool g_pools[kMaxDevices];
 std::mutex g_pools_mu;
 
-using PhaseLock = std::unique_lock<std::mutex>;
+// what a phase needs from its slot (0 = not needed)
+struct SlotNeed {
+    size_t field_elems = 0, scratch_elems = 0, lowbuf_elems = 0, planes_bytes = 0, hist_elems = 0;
+};
 
-// pool buffers: call with pool->phase held
-int ensure_scratch(wr_ctx* c, size_t n)
+template <class T>
+hipError_t grow(T** buf, size_t* have, size_t want)
 {
-    DevPool* p = c->pool;
-    if (p->scratch_elems >= n) return WR_OK;
-    if (p->scratch) HIPCHK(hipFree(p->scratch));
-    p->scratch = nullptr; p->scratch_elems = 0;
-    HIPCHK(hipMalloc(&p->scratch, n * sizeof(double)));
-    p->scratch_elems = n;
-    return WR_OK;
+    if (*have >= want) return hipSuccess;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *have = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(buf), want * sizeof(T));
+    if (e == hipSuccess) *have = want;
+    return e;
 }
 
-int ensure_planes(wr_ctx* c, size_t bytes)
+hipError_t slot_ensure(Slot* s, const SlotNeed& need)
 {
-    DevPool* p = c->pool;
-    if (p->planes_bytes >= bytes) return WR_OK;
-    if (p->planes) HIPCHK(hipFree(p->planes));
-    p->planes = nullptr; p->planes_bytes = 0;
-    HIPCHK(hipMalloc(&p->planes, bytes));
-    p->planes_bytes = bytes;
-    return WR_OK;
+    hipError_t e;
+    if ((e = grow(&s->field, &s->field_elems, need.field_elems)) != hipSuccess) return e;
+    if ((e = grow(&s->scratch, &s->scratch_elems, need.scratch_elems)) != hipSuccess) return e;
+    if ((e = grow(&s->lowbuf, &s->lowbuf_elems, need.lowbuf_elems)) != hipSuccess) return e;
+    if ((e = grow(&s->planes, &s->planes_bytes, need.planes_bytes)) != hipSuccess) return e;
+    if ((e = grow(&s->hist, &s->hist_elems, need.hist_elems)) != hipSuccess) return e;
+    return hipSuccess;
 }
+
+// RAII ownership of a slot.  Free slots that already hold buffers are handed out first; a further
+// slot is populated only when all of those are busy.  If the device has no memory left for another
+// slot, the pool shrinks to the slots it has and the caller waits for one of them.
+class SlotLease {
+public:
+    SlotLease() = default;
+    SlotLease(const SlotLease&) = delete;
+    SlotLease& operator=(const SlotLease&) = delete;
+    ~SlotLease() { release(); }
+
+    // nowait: return 1 instead of blocking; spare: only succeed if that many further slots stay free
+    int acquire(wr_ctx* c, const SlotNeed& need, bool nowait = false, int spare = 0)
+    {
+        DevPool* p = c->pool;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(p->mu);
+                for (;;) {
+                    Slot* pick = nullptr;
+                    int nfree = 0;
+                    for (int i = 0; i < p->max_slots; i++) {
+                        Slot& s = p->slots[i];
+                        if (s.busy || s.disabled) continue;
+                        nfree++;
+                        // populated slots first; a further one is populated only when all of those are busy
+                        if (!pick || (s.allocated() && !pick->allocated())) pick = &s;
+                    }
+                    if (pick && nfree > spare) { pick->busy = true; slot_ = pick; pool_ = p; break; }
+                    if (nowait) return 1;
+                    p->cv.wait(lk);
+                }
+            }
+            const bool fresh = !slot_->allocated();
+            const hipError_t e = slot_ensure(slot_, need);
+            if (e == hipSuccess) { if (fresh) g_stat[WR_STAT_SLOTS_POPULATED]++; return WR_OK; }
+            (void)hipGetLastError();
+            std::unique_lock<std::mutex> lk(p->mu);
+            int others = 0;
+            for (int i = 0; i < p->max_slots; i++)
+                if (&p->slots[i] != slot_ && !p->slots[i].disabled && p->slots[i].allocated()) others++;
+            slot_->release_buffers();
+            // out of device memory with other slots populated: keep to those and wait for one of them
+            const bool retry = e == hipErrorOutOfMemory && others > 0;
+            if (retry) slot_->disabled = true;
+            slot_->busy = false; slot_ = nullptr;
+            p->cv.notify_all();
+            if (!retry) return fail(WR_ERR_HIP, std::string("device work space: ") + hipGetErrorString(e));
+            if (nowait) return 1;
+        }
+    }
+    void release()
+    {
+        if (!slot_) return;
+        { std::lock_guard<std::mutex> lk(pool_->mu); slot_->busy = false; }
+        pool_->cv.notify_all();
+        slot_ = nullptr;
+    }
+    Slot* get() const { return slot_; }
+    Slot* operator->() const { return slot_; }
+    explicit operator bool() const { return slot_ != nullptr; }
+
+private:
+    Slot* slot_ = nullptr;
+    DevPool* pool_ = nullptr;
+};
+
+using StageLock = std::unique_lock<std::mutex>;
 
 // pinned staging of plane l, allocated the first time a field needs that many planes (a 1024^3
 // field at tol 1e-3 needs 3 GiB here, not 8)
@@ -182,79 +294,55 @@ int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
     return c->enc_buf[l] ? WR_OK : fail(WR_ERR_ARG, "out of host memory for the coded stream");
 }
 
-int ensure_hist(wr_ctx* c, size_t elems)
+int ensure_host_hist(wr_ctx* c, size_t elems)
 {
-    DevPool* p = c->pool;
-    if (p->hist_elems < elems) {
-        if (p->hist) HIPCHK(hipFree(p->hist));
-        p->hist = nullptr; p->hist_elems = 0;
-        HIPCHK(hipMalloc(&p->hist, elems * sizeof(uint16_t)));
-        p->hist_elems = elems;
-    }
-    if (c->h_hist_elems < elems) {
-        if (c->h_hist) HIPCHK(hipHostFree(c->h_hist));
-        c->h_hist = nullptr; c->h_hist_elems = 0;
-        HIPCHK(hipHostMalloc(&c->h_hist, elems * sizeof(uint16_t), hipHostMallocDefault));
-        c->h_hist_elems = elems;
-    }
+    if (c->h_hist_elems >= elems) return WR_OK;
+    if (c->h_hist) HIPCHK(hipHostFree(c->h_hist));
+    c->h_hist = nullptr; c->h_hist_elems = 0;
+    HIPCHK(hipHostMalloc(&c->h_hist, elems * sizeof(uint16_t), hipHostMallocDefault));
+    c->h_hist_elems = elems;
     return WR_OK;
 }
 
-int ensure_lowbuf(wr_ctx* c, size_t n)
+bool use_fused(int nx, int ny, int nz, int lvl)
 {
-    DevPool* p = c->pool;
-    if (p->lowbuf_elems >= n) return WR_OK;
-    if (p->lowbuf) HIPCHK(hipFree(p->lowbuf));
-    p->lowbuf = nullptr; p->lowbuf_elems = 0;
-    HIPCHK(hipMalloc(&p->lowbuf, n * sizeof(double)));
-    p->lowbuf_elems = n;
-    return WR_OK;
+    return wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED");
 }
 
-// Forward transform of d_fld.  The fused path is out of place: the coefficients land in the
-// context's scratch buffer and *coef points there; the generic path works in place.
-int forward_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl, double** coef)
+// work space a transform of this shape needs next to the field itself
+void transform_need(int nx, int ny, int nz, int lvl, SlotNeed* need)
 {
-    const size_t n = (size_t)nx * ny * nz;
-    if (int rc = ensure_scratch(c, n)) return rc;
-    *coef = d_fld;
-    if (wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED")) {
-        if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
-        if (lvl > 0) wrk::transform_fwd_fused(d_fld, c->pool->scratch, c->pool->lowbuf, nx, ny, nz, c->stream);
-        else wrk::transform_inv_fused(d_fld, c->pool->scratch, c->pool->lowbuf, nx, ny, nz, c->stream);
-        *coef = c->pool->scratch;
+    need->scratch_elems = (size_t)nx * ny * nz;
+    if (use_fused(nx, ny, nz, lvl)) need->lowbuf_elems = wrk::fused_lowbuf_elems(nx, ny, nz);
+}
+
+// Forward (lvl > 0) or inverse (lvl < 0) transform of d_fld.  The fused path is out of place: the result
+// lands in the slot's scratch buffer and *out points there; the general path works in place.
+void run_transform(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int lvl, double** out)
+{
+    *out = d_fld;
+    if (use_fused(nx, ny, nz, lvl)) {
+        if (lvl > 0) wrk::transform_fwd_fused(d_fld, s->scratch, s->lowbuf, nx, ny, nz, c->stream);
+        else wrk::transform_inv_fused(d_fld, s->scratch, s->lowbuf, nx, ny, nz, c->stream);
+        *out = s->scratch;
     } else {
-        wrk::transform(d_fld, c->pool->scratch, nx, ny, nz, lvl, c->stream);
+        wrk::transform(d_fld, s->scratch, nx, ny, nz, lvl, c->stream);
     }
-    return WR_OK;
 }
 
 // decoder back end: acc = sum of planes, then the inverse transform, result in d_fld.
 // Fused path: accumulate into the scratch buffer and transform out of place into d_fld.
-// Records ev_a / ev_b / ev_c around the two stages (for the timings) when tm is given.
-int inverse_from_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wlev, const wrk::DequantParams& p,
-                        wr_timings* tm)
+// Records ev_a / ev_b / ev_c around the two stages (for the timings).
+int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int wlev, const wrk::DequantParams& p)
 {
     const size_t n = (size_t)nx * ny * nz;
-    if (int rc = ensure_scratch(c, n)) return rc;
-    const bool fused = wlev == 4 && wrk::fused_ok(nx, ny, nz, -4) && !getenv("WR_NO_FUSED");
-    if (fused) if (int rc = ensure_lowbuf(c, wrk::fused_lowbuf_elems(nx, ny, nz))) return rc;
-    if (tm) HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    wrk::dequant_accum(fused ? c->pool->scratch : d_fld, n, p, c->stream);
-    if (tm) HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    if (fused) wrk::transform_inv_fused(c->pool->scratch, d_fld, c->pool->lowbuf, nx, ny, nz, c->stream);
-    else wrk::transform(d_fld, c->pool->scratch, nx, ny, nz, -wlev, c->stream);
-    if (tm) HIPCHK(hipEventRecord(c->ev_c, c->stream));
-    return WR_OK;
-}
-
-int ensure_field(wr_ctx* c, size_t n)
-{
-    if (c->field_elems >= n) return WR_OK;
-    if (c->d_field) HIPCHK(hipFree(c->d_field));
-    c->d_field = nullptr; c->field_elems = 0;
-    HIPCHK(hipMalloc(&c->d_field, n * sizeof(double)));
-    c->field_elems = n;
+    const bool fused = wlev == 4 && use_fused(nx, ny, nz, -4);
+    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
+    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (fused) wrk::transform_inv_fused(s->scratch, d_fld, s->lowbuf, nx, ny, nz, c->stream);
+    else wrk::transform(d_fld, s->scratch, nx, ny, nz, -wlev, c->stream);
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
     return WR_OK;
 }
 
@@ -262,11 +350,14 @@ int ensure_field(wr_ctx* c, size_t n)
 // values from the reduction; if the minimum is a zero, its sign is that of the LAST zero in
 // memory order (glibc fmin keeps the later of equal operands -- oracle/wr_oracle.c:wro_minmax).
 // `pending` = the reduction has already been enqueued into d_result by a fused kernel.
+// Waits on an event recorded right behind the read-back, so kernels enqueued afterwards do not
+// delay the answer.
 int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn, double* mx)
 {
     if (!pending) wrk::minmax(d_x, n, c->d_partial, c->d_result, c->stream);
     HIPCHK(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventRecord(c->ev_mm, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_mm));
     double lo = c->h_result[0], hi = c->h_result[1];
     if (lo == 0.0) {
         wrk::last_zero_index(d_x, n, c->d_idx, c->stream);
@@ -328,11 +419,10 @@ double abs_tolerance(double tolrel, const Prologue& p)
     return tolabs;
 }
 
-int check_dims(int nx, int ny, int nz, const void* ptr)
+int check_dims(int nx, int ny, int nz, const void* dev_ptr)
 {
     if (nx < 1 || ny < 1 || nz < 1) return fail(WR_ERR_ARG, "non-positive dimension");
-    if (ny > 65535 || nz > 65535) return fail(WR_ERR_UNSUPPORTED, "ny, nz must be <= 65535");
-    if (((uintptr_t)ptr) & 15) return fail(WR_ERR_ARG, "device field pointer must be 16-byte aligned");
+    if (((uintptr_t)dev_ptr) & 15) return fail(WR_ERR_ARG, "device field pointer must be 16-byte aligned");
     return WR_OK;
 }
 
@@ -341,6 +431,14 @@ struct Sem {  // tiny counting semaphore limiting concurrent range-coder threads
     explicit Sem(int k) : n(k) {}
     void acquire() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return n > 0; }); n--; }
     void release() { { std::lock_guard<std::mutex> l(m); n++; } cv.notify_one(); }
+};
+
+// joins what it holds on every way out of a scope (a std::thread that is destroyed while joinable
+// terminates the process)
+struct Workers {
+    std::vector<std::thread> v;
+    ~Workers() { join(); }
+    void join() { for (auto& t : v) if (t.joinable()) t.join(); v.clear(); }
 };
 
 }  // namespace
@@ -359,27 +457,40 @@ int wr_device_count(void)
     return n;
 }
 
-void wr_set_verbosity(int level) { g_verbose = level ? 1 : 0; }
-void wr_set_threads(int nthreads) { g_threads = nthreads < 1 ? 1 : nthreads; g_enc_threads = 0; }
-void wr_set_encoder_threads(int nthreads) { g_enc_threads = nthreads < 0 ? 0 : nthreads; }
+void wr_set_verbosity(int level) { g_verbose.store(level ? 1 : 0); }
+void wr_set_threads(int nthreads) { g_threads.store(nthreads < 1 ? 1 : nthreads); g_enc_threads.store(0); }
+void wr_set_encoder_threads(int nthreads) { g_enc_threads.store(nthreads < 0 ? 0 : nthreads); }
+void wr_set_writeback_residual(int on) { g_writeback.store(on ? 1 : 0); }
+unsigned long wr_stat(int what) { return (what >= 0 && what < 4) ? g_stat[what].load() : 0; }
 
-int wr_ctx_create(wr_ctx** out, int device, void* hip_stream)
+int wr_set_device_slots(int device, int nslots)
 {
-    if (!out) return fail(WR_ERR_ARG, "null ctx pointer");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev < 1)
-        return fail(WR_ERR_HIP, std::string("no usable HIP device (") + hipGetErrorString(e) +
-                                    "): libwaverange_amd has no CPU fallback");
-    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(WR_ERR_ARG, "device index out of range");
-    wr_ctx* c = new wr_ctx;
-    c->device = device;
-    c->pool = &g_pools[device];
-    { std::lock_guard<std::mutex> lk(g_pools_mu); c->pool->users++; }
+    if (device < 0 || device >= kMaxDevices) return fail(WR_ERR_ARG, "device index out of range");
+    if (nslots < 1) nslots = 1;
+    if (nslots > kMaxSlots) nslots = kMaxSlots;
+    DevPool* p = &g_pools[device];
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (int i = nslots; i < kMaxSlots; i++)
+        if (p->slots[i].busy || p->slots[i].allocated()) return fail(WR_ERR_ARG, "slots beyond the new count are in use");
+    p->max_slots = nslots;
+    for (Slot& s : p->slots) s.disabled = false;
+    return WR_OK;
+}
+
+static int ctx_init(wr_ctx* c, int device, void* hip_stream)
+{
     HIPCHK(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        DevPool* p = c->pool;
+        if (!p->up) {
+            if (const char* e = getenv("WR_SLOTS")) { const int k = atoi(e); if (k >= 1) p->max_slots = k > kMaxSlots ? kMaxSlots : k; }
+            HIPCHK(hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
+        }
+        if (!p->down) HIPCHK(hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
+    }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_partial, 2 * wrk::minmax_partials() * sizeof(double)));
     HIPCHK(hipMalloc(&c->d_result, 4 * sizeof(double)));
     HIPCHK(hipMalloc(&c->d_idx, sizeof(unsigned long long)));
@@ -390,6 +501,34 @@ int wr_ctx_create(wr_ctx** out, int device, void* hip_stream)
     }
     HIPCHK(hipEventCreate(&c->ev_a)); HIPCHK(hipEventCreate(&c->ev_b));
     HIPCHK(hipEventCreate(&c->ev_c)); HIPCHK(hipEventCreate(&c->ev_d));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_h2d0)); HIPCHK(hipEventCreate(&c->ev_h2d1));
+    HIPCHK(hipEventCreate(&c->ev_d2h0)); HIPCHK(hipEventCreate(&c->ev_d2h1));
+    return WR_OK;
+}
+
+int wr_ctx_create(wr_ctx** out, int device, void* hip_stream)
+{
+    if (!out) return fail(WR_ERR_ARG, "null ctx pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(WR_ERR_HIP, std::string("no usable HIP device (") + hipGetErrorString(e) +
+                                    "): libwaverange_amd has no CPU fallback");
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(WR_ERR_ARG, "device index out of range");
+    wr_ctx* c = new (std::nothrow) wr_ctx;
+    if (!c) return fail(WR_ERR_ARG, "out of host memory");
+    c->device = device;
+    c->pool = &g_pools[device];
+    { std::lock_guard<std::mutex> lk(g_pools_mu); c->pool->users++; }
+    const int rc = ctx_init(c, device, hip_stream);
+    if (rc != WR_OK) {
+        const std::string msg = g_err;
+        wr_ctx_destroy(c);  // releases whatever was created, and the pool reference
+        g_err = msg;
+        return rc;
+    }
     *out = c;
     return WR_OK;
 }
@@ -398,28 +537,30 @@ void wr_ctx_destroy(wr_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->copy);
-    (void)hipFree(c->d_field); (void)hipFree(c->d_cutoff);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_cutoff);
     (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
-    (void)hipHostFree(c->h_result); (void)hipHostFree(c->h_hist);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_hist) (void)hipHostFree(c->h_hist);
     for (int l = 0; l < WR_NLAYMAX; l++) {
         if (c->h_plane[l]) { if (c->h_plane_pinned[l]) (void)hipHostFree(c->h_plane[l]); else free(c->h_plane[l]); }
         free(c->enc_buf[l]);
     }
-    for (int i = 0; i < WR_NLAYMAX; i++) { (void)hipEventDestroy(c->ev_plane[i]); (void)hipEventDestroy(c->ev_copy[i]); }
-    (void)hipEventDestroy(c->ev_a); (void)hipEventDestroy(c->ev_b);
-    (void)hipEventDestroy(c->ev_c); (void)hipEventDestroy(c->ev_d);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
-    (void)hipStreamDestroy(c->copy);
+    for (int i = 0; i < WR_NLAYMAX; i++) {
+        if (c->ev_plane[i]) (void)hipEventDestroy(c->ev_plane[i]);
+        if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
+    }
+    for (hipEvent_t ev : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_mm, c->ev_h2d0, c->ev_h2d1, c->ev_d2h0, c->ev_d2h1})
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     {   // the last context on a device releases the shared work space
         std::lock_guard<std::mutex> lk(g_pools_mu);
         DevPool* p = c->pool;
         if (--p->users == 0) {
-            std::lock_guard<std::mutex> ph(p->phase);
-            (void)hipFree(p->scratch); (void)hipFree(p->planes); (void)hipFree(p->lowbuf); (void)hipFree(p->hist);
-            p->scratch = nullptr; p->planes = nullptr; p->lowbuf = nullptr; p->hist = nullptr;
-            p->scratch_elems = p->planes_bytes = p->lowbuf_elems = p->hist_elems = 0;
+            std::lock_guard<std::mutex> sl(p->mu);
+            if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); p->up = nullptr; }
+            if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); p->down = nullptr; }
+            for (Slot& s : p->slots) s.release_buffers();
         }
     }
     delete c;
@@ -429,7 +570,6 @@ int wr_ctx_sync(wr_ctx* c)
 {
     if (int rc = ctx_bind(c)) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipStreamSynchronize(c->copy));
     return WR_OK;
 }
 
@@ -446,6 +586,18 @@ int wr_dev_free(wr_ctx* c, void* ptr)
 {
     if (int rc = ctx_bind(c)) return rc;
     HIPCHK(hipFree(ptr));
+    return WR_OK;
+}
+
+int wr_host_alloc(void** ptr, size_t bytes)
+{
+    HIPCHK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return WR_OK;
+}
+
+int wr_host_free(void* ptr)
+{
+    HIPCHK(hipHostFree(ptr));
     return WR_OK;
 }
 
@@ -468,7 +620,7 @@ int wr_dev_download(wr_ctx* c, void* dst, const void* src, size_t bytes)
 int wr_dev_copy(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;
-    PhaseLock ph(c->pool->phase);  // a device phase like any other: keeps it off other contexts' transforms
+    StageLock cu(c->pool->cu_mu);  // a kernel stage like any other: keeps it off other contexts' transforms
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return WR_OK;
@@ -490,13 +642,17 @@ int wr_dev_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl)
 {
     if (int rc = ctx_bind(c)) return rc;
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
-    double* coef = nullptr;
-    PhaseLock ph(c->pool->phase);
-    if (int rc = forward_transform(c, d_fld, nx, ny, nz, lvl, &coef)) return rc;  // handles lvl < 0 too
-    if (coef != d_fld)
-        HIPCHK(hipMemcpyAsync(d_fld, coef, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    SlotNeed need;
+    transform_need(nx, ny, nz, lvl, &need);
+    SlotLease slot;
+    if (int rc = slot.acquire(c, need)) return rc;
+    StageLock cu(c->pool->cu_mu);
+    double* res = nullptr;
+    run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res);
+    if (res != d_fld)
+        HIPCHK(hipMemcpyAsync(d_fld, res, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));  // the shared work space is released with the lock
+    HIPCHK(hipStreamSynchronize(c->stream));  // the work space goes back with the lease
     return WR_OK;
 }
 
@@ -547,8 +703,6 @@ size_t wr_plane_pitch(size_t n) { return (n + 255) & ~(size_t)255; }
 
 namespace {
 
-// Device part of the encoder.  on_plane(l, last) is called right after plane l's kernel has
-// been enqueued and ev_plane[l] recorded (the full pipeline hooks its D2H + coder thread in).
 // local cutoff description (mx*my*mz == 1: uniform cutoff, the benchmark path)
 struct Cutoff {
     int mx = 1, my = 1, mz = 1;
@@ -556,9 +710,13 @@ struct Cutoff {
     int count() const { return mx * my * mz; }
 };
 
+// Kernel stage of the encoder (call with the slot leased and DevPool::cu_mu held).  on_plane(l, last) is
+// called right after plane l's quantizer kernel and the read-back of the next plane's min/max have
+// been enqueued (the full pipeline hooks the histograms, the D2H and the coder thread in there).
+// *resid = where the coefficient array / residual lives afterwards.
 template <class OnPlane>
-int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
-                       uint8_t* d_planes, wr_enc_info* info, wr_timings* tm, OnPlane on_plane)
+int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
+                       uint8_t* d_planes, wr_enc_info* info, wr_timings* tm, OnPlane on_plane, double** resid)
 {
     // minimum cutoff = the global relative tolerance (wrappers.cpp:288-290)
     double tolrel = cut.vec[0];
@@ -575,8 +733,8 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
     }
     const size_t n = (size_t)nx * ny * nz;
     const size_t pitch = wr_plane_pitch(n);
-    if (int rc = ensure_scratch(c, n)) return rc;
     Prologue p;
+    *resid = d_fld;
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     if (int rc = prologue(c, d_fld, n, wtflag, info, &p)) return rc;
     if (verbose()) printf("Wavelet decomposition...\n");
@@ -585,8 +743,8 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
         return WR_OK;
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    double* const d_in = d_fld;
-    if (int rc = forward_transform(c, d_in, nx, ny, nz, (int)info->wlev, &d_fld)) return rc;  // d_fld := coefficients
+    run_transform(c, slot, d_fld, nx, ny, nz, (int)info->wlev, &d_fld);  // d_fld := coefficients
+    *resid = d_fld;
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     if (verbose()) printf("Range encoding...\n");
     info->tolabs = abs_tolerance(tolrel, p);
@@ -608,7 +766,7 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
         info->minval_vec[ilay] = s.minval;
         info->deps_vec[ilay] = s.deps;
         if (verbose()) { printf("min=%g max=%g\n", lo, hi); printf("ilay=%u deps=%g\n", ilay, s.deps); }
-        const bool resid = !s.last || c->keep_residual;
+        const bool resid_upd = !s.last || c->keep_residual;
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
         if (local) {
             wrk::LocalCutoff lc;
@@ -621,25 +779,25 @@ int encode_planes_core(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtf
             wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, lc,
                                       c->d_partial, c->d_result, c->stream);
         } else
-        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, resid,
+        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, resid_upd,
                             c->d_partial, c->d_result, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
-        HIPCHK(hipEventRecord(c->ev_plane[ilay], c->stream));
         HIPCHK(hipGetLastError());
+        // the next plane's min/max goes to the host first; what on_plane enqueues runs behind it
+        if (!s.last)
+            HIPCHK(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->ev_mm, c->stream));
         if (int rc = on_plane(ilay, s.last)) return rc;
         ilay++;
-        if (s.last) {
-            HIPCHK(hipEventSynchronize(c->ev_b));
-            HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); quant_ms += ms;
-            break;
-        }
-        if (int rc = read_minmax(c, d_fld, n, true, &lo, &hi)) return rc;
+        HIPCHK(hipEventSynchronize(c->ev_mm));
         HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); quant_ms += ms;
+        if (s.last) break;
+        lo = c->h_result[0]; hi = c->h_result[1];
+        if (lo == 0.0)  // sign of a zero minimum: rare path, goes through the full read-back
+            if (int rc = read_minmax(c, d_fld, n, true, &lo, &hi)) return rc;
     }
     info->nlay = (unsigned char)ilay;
     if (tm) tm->quant_ms = quant_ms;
-    if (c->keep_residual && d_fld != d_in)  // leave the residual where the reference leaves it
-        HIPCHK(hipMemcpyAsync(d_in, d_fld, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return WR_OK;
 }
 
@@ -654,13 +812,20 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     if ((uintptr_t)d_planes & 15) return fail(WR_ERR_ARG, "plane buffer must be 16-byte aligned");
     std::lock_guard<std::mutex> lk(c->mu);
-    PhaseLock ph(c->pool->phase);
+    SlotNeed need;
+    transform_need(nx, ny, nz, wtflag ? kWavLvl : 0, &need);
+    SlotLease slot;
+    if (int rc = slot.acquire(c, need)) return rc;
+    StageLock cu(c->pool->cu_mu);
     Cutoff cut; cut.vec = &tolrel;
-    int rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, d_planes, info, nullptr,
-                                [](unsigned, bool) { return WR_OK; });
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return WR_OK;
+    double* resid = nullptr;
+    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, d_planes, info, nullptr,
+                                [](unsigned, bool) { return WR_OK; }, &resid);
+    if (rc == WR_OK && resid != d_fld && info->nlay)  // d_fld holds the residual afterwards (header contract)
+        if (hipMemcpyAsync(d_fld, resid, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            rc = fail(WR_ERR_HIP, "residual copy failed");
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const unsigned char* d_planes,
@@ -676,8 +841,11 @@ int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const
         return WR_OK;
     }
     if (info->nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
-    PhaseLock ph(c->pool->phase);
-    if (int rc = ensure_scratch(c, n)) return rc;
+    SlotNeed need;
+    transform_need(nx, ny, nz, info->wlev ? -kWavLvl : 0, &need);
+    SlotLease slot;
+    if (int rc = slot.acquire(c, need)) return rc;
+    StageLock cu(c->pool->cu_mu);
     wrk::DequantParams p;
     memset(&p, 0, sizeof p);
     p.nlay = info->nlay;
@@ -686,36 +854,29 @@ int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const
         p.deps[l] = info->deps_vec[l];
         p.minval[l] = info->minval_vec[l];
     }
-    if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, nullptr)) return rc;
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return WR_OK;
+    int rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
+    if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
-static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
-                              wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm);
+}  // extern "C"
 
-int wr_encode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, double tolrel,
-                     wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm)
-{
-    Cutoff cut; cut.vec = &tolrel;
-    return encode_device_impl(c, d_fld, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
-}
+namespace {
 
-int wr_encode_device_local(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, int mx, int my, int mz,
-                           const double* cutoffvec, wr_enc_info* info, unsigned char* data_enc, size_t cap,
-                           wr_timings* tm)
-{
-    if (mx < 1 || my < 1 || mz < 1 || !cutoffvec) return fail(WR_ERR_ARG, "bad local cutoff description");
-    Cutoff cut; cut.mx = mx; cut.my = my; cut.mz = mz; cut.vec = cutoffvec;
-    return encode_device_impl(c, d_fld, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
-}
+// where the field of an encode call comes from / the field of a decode call goes to
+struct FieldRef {
+    double* dev = nullptr;   // device-resident (caller's buffer), or
+    double* host = nullptr;  // host buffer (pinned or pageable): staged through the slot
+};
 
-static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
-                              wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm)
+int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut, wr_enc_info* info,
+                unsigned char* data_enc, size_t cap, wr_timings* tm)
 {
     if (int rc = ctx_bind(c)) return rc;
-    if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
+    if (int rc = check_dims(nx, ny, nz, fld.dev)) return rc;
+    if (!fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
+    if (cut.mx < 1 || cut.my < 1 || cut.mz < 1 || !cut.vec) return fail(WR_ERR_ARG, "bad local cutoff description");
     std::lock_guard<std::mutex> lk(c->mu);
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
@@ -724,14 +885,14 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
     // per-60000-symbol-block byte histograms, counted on the GPU next to the quantizer and shipped
     // with the plane, so that the host coder starts every block with its model ready
     const size_t hist_per_plane = (n / wrrc::kBlock + 1) * 256;
+    DevPool* const pool = c->pool;
 
-    std::vector<std::thread> workers;
     size_t lens[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
     std::string logs[WR_NLAYMAX];
     Sem sem(encoder_threads());
     const int dev = c->device;
-    double t_gpu_done = 0;
+    Workers workers;
 
     // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
     // on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
@@ -760,40 +921,100 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
                 logs[l] = b;
             }
     };
-    auto on_plane = [&](unsigned l, bool) -> int {
-        // plane l: device -> pinned host on the copy stream
-        HIPCHK(hipStreamWaitEvent(c->copy, c->ev_plane[l], 0));
-        wrk::block_histograms(c->pool->planes + l * pitch, n, c->pool->hist + l * hist_per_plane, c->copy);
-        HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, c->pool->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
-                              hipMemcpyDeviceToHost, c->copy));
-        if (int rc = ensure_host_plane(c, (int)l, pitch)) return rc;
-        if (int rc = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return rc;
-        HIPCHK(hipMemcpyAsync(c->h_plane[l], c->pool->planes + l * pitch, n, hipMemcpyDeviceToHost, c->copy));
-        HIPCHK(hipEventRecord(c->ev_copy[l], c->copy));
-        if (per_plane) workers.emplace_back(code_group, l, l + 1);
-        return WR_OK;
-    };
-    int rc;
-    double t_phase = 0;
-    {
-        PhaseLock gpu(c->pool->phase);
+
+    SlotNeed need;
+    transform_need(nx, ny, nz, wtflag ? kWavLvl : 0, &need);
+    if (fld.host) need.field_elems = n;
+    need.planes_bytes = pitch * WR_NLAYMAX;
+    need.hist_elems = hist_per_plane * WR_NLAYMAX;
+    if (int rc = ensure_host_hist(c, hist_per_plane * WR_NLAYMAX)) return rc;
+
+    int rc = WR_OK;
+    double t_phase = 0, t_gpu_done = 0;
+    bool planes_in_flight = false;
+    try {
+        SlotLease slot;
+        if ((rc = slot.acquire(c, need)) != WR_OK) return rc;
         t_phase = now();
-        rc = ensure_planes(c, pitch * WR_NLAYMAX);
-        if (!rc) rc = ensure_hist(c, hist_per_plane * WR_NLAYMAX);
-        if (!rc) rc = encode_planes_core(c, d_fld, nx, ny, nz, wtflag, cut, c->pool->planes, info, &local, on_plane);
-        // The phase ends when the planes are on the host: the plane buffer is shared with the other
-        // contexts on this device, and with many contexts in a process the runtime runs the copies as blit kernels, which are
-        // better kept off other contexts' transforms (tens of ms; coder threads start per plane regardless)
-        (void)hipStreamSynchronize(c->copy);
-        (void)hipStreamSynchronize(c->stream);
+        double* d_fld = fld.dev;
+        if (fld.host) {
+            // ---- stage "up": the field goes host -> device on the device's upload stream
+            d_fld = slot->field;
+            {
+                StageLock up(pool->up_mu);
+                HIPCHK(hipEventRecord(c->ev_h2d0, pool->up));
+                HIPCHK(hipMemcpyAsync(d_fld, fld.host, n * sizeof(double), hipMemcpyHostToDevice, pool->up));
+                HIPCHK(hipEventRecord(c->ev_h2d1, pool->up));
+            }
+            HIPCHK(hipEventSynchronize(c->ev_h2d1));  // before the kernel stage is claimed: others may compute meanwhile
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev_h2d0, c->ev_h2d1)); local.h2d_ms = ms;
+        }
+        double* resid = d_fld;
+        bool first_copy = true;
+        auto on_plane = [&](unsigned l, bool) -> int {
+            // histograms on the kernel stream (behind the min/max read-back), then plane l: device ->
+            // pinned host on the device's download stream, which never runs a kernel
+            wrk::block_histograms(slot->planes + l * pitch, n, slot->hist + l * hist_per_plane, c->stream);
+            HIPCHK(hipEventRecord(c->ev_plane[l], c->stream));
+            if (int r = ensure_host_plane(c, (int)l, pitch)) return r;
+            if (int r = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return r;
+            {
+                StageLock down(pool->down_mu);
+                HIPCHK(hipStreamWaitEvent(pool->down, c->ev_plane[l], 0));
+                if (first_copy) { HIPCHK(hipEventRecord(c->ev_d2h0, pool->down)); first_copy = false; }
+                HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
+                                      hipMemcpyDeviceToHost, pool->down));
+                HIPCHK(hipMemcpyAsync(c->h_plane[l], slot->planes + l * pitch, n, hipMemcpyDeviceToHost, pool->down));
+                HIPCHK(hipEventRecord(c->ev_copy[l], pool->down));
+            }
+            planes_in_flight = true;
+            if (per_plane) workers.v.emplace_back(code_group, l, l + 1);
+            return WR_OK;
+        };
+        {
+            // ---- stage "kernels"
+            StageLock cu(pool->cu_mu);
+            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, slot->planes, info, &local, on_plane, &resid);
+            if (rc == WR_OK && info->nlay) (void)hipEventSynchronize(c->ev_plane[info->nlay - 1]);
+            else (void)hipStreamSynchronize(c->stream);
+        }
+        // ---- stage "down": the plane copies were queued as the planes appeared; the residual follows them
+        if (rc == WR_OK && info->nlay) {
+            if (c->keep_residual && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
+                HIPCHK(hipMemcpyAsync(fld.dev, resid, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+            }
+            {
+                StageLock down(pool->down_mu);
+                if (c->keep_residual && fld.host)
+                    HIPCHK(hipMemcpyAsync(fld.host, resid, n * sizeof(double), hipMemcpyDeviceToHost, pool->down));
+                HIPCHK(hipEventRecord(c->ev_d2h1, pool->down));
+            }
+            HIPCHK(hipEventSynchronize(c->ev_d2h1));
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->ev_d2h0, c->ev_d2h1) == hipSuccess) local.d2h_ms = ms;
+        } else if (planes_in_flight) {
+            StageLock down(pool->down_mu);
+            (void)hipStreamSynchronize(pool->down);  // error path: nothing of this call may stay queued on the slot
+        }
+        t_gpu_done = now();
+        // the slot goes back here: its planes are on the host
+    } catch (const std::exception& e) {
+        workers.join();
+        return fail(WR_ERR_ARG, std::string("encode: ") + e.what());
     }
-    t_gpu_done = now();
-    if (!per_plane && rc == WR_OK && info->nlay) {
-        const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)encoder_threads());
-        for (unsigned g = 0; g < groups; g++)
-            workers.emplace_back(code_group, g * info->nlay / groups, (g + 1) * info->nlay / groups);
+    if (rc == WR_OK && !per_plane && info->nlay) {
+        try {
+            const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)encoder_threads());
+            for (unsigned g = 0; g < groups; g++)
+                workers.v.emplace_back(code_group, g * info->nlay / groups, (g + 1) * info->nlay / groups);
+        } catch (const std::exception& e) {
+            workers.join();
+            return fail(WR_ERR_ARG, std::string("encode: ") + e.what());
+        }
     }
-    for (auto& w : workers) w.join();
+    workers.join();
     if (rc) return rc;
     const double t_coded = now();
     // concatenate the plane streams (wrappers.cpp:412-427); gigabytes at 1024^3, so one copier per plane
@@ -805,110 +1026,259 @@ static int encode_device_impl(wr_ctx* c, double* d_fld, int nx, int ny, int nz, 
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
     }
     if (total > cap) return fail(WR_ERR_OVERFLOW, "Error: encoded array is too large. Use larger SAFETY_BUFFER_FACTOR");
-    {
-        std::vector<std::thread> copiers;
+    try {
+        Workers copiers;
         for (unsigned l = 1; l < info->nlay; l++)
-            copiers.emplace_back([&, l]() { memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]); });
+            copiers.v.emplace_back([&, l]() { memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]); });
         if (info->nlay) memcpy(data_enc, c->enc_buf[0], lens[0]);
-        for (auto& t : copiers) t.join();
+    } catch (const std::exception&) {  // no thread to be had: copy here
+        for (unsigned l = 0; l < info->nlay; l++) memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]);
     }
     if (verbose())
         for (unsigned l = 0; l < info->nlay; l++) fputs(logs[l].c_str(), stdout);
     info->ntot_enc = total;
     local.total = now() - t0;
-    local.gpu = t_gpu_done - t_phase;  // without the wait for the device
+    local.wait = t_phase - t0;
+    local.gpu = t_gpu_done - t_phase;  // without the wait for a slot
     local.transfer = (t_coded - t_gpu_done) - local.rangecoder;
     if (local.transfer < 0) local.transfer = 0;
     if (tm) *tm = local;
     return WR_OK;
 }
 
-int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_enc_info* info,
-                     const unsigned char* data_enc, wr_timings* tm)
+int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_info* info, const unsigned char* data_enc,
+                size_t data_len, wr_timings* tm)
 {
     if (int rc = ctx_bind(c)) return rc;
-    if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
+    if (int rc = check_dims(nx, ny, nz, fld.dev)) return rc;
+    if (!fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
     std::lock_guard<std::mutex> lk(c->mu);
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
     const size_t pitch = wr_plane_pitch(n);
     wr_timings local; memset(&local, 0, sizeof local);
+    DevPool* const pool = c->pool;
     if (info->ntot_enc == 0) {  // wrappers.cpp:462-469
-        wrk::fill(d_fld, n, info->midval, c->stream);
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (fld.host) for (size_t j = 0; j < n; j++) fld.host[j] = info->midval;
+        else { wrk::fill(fld.dev, n, info->midval, c->stream); HIPCHK(hipStreamSynchronize(c->stream)); }
         local.total = now() - t0;
         if (tm) *tm = local;
         return WR_OK;
     }
     const int nlay = info->nlay;
     if (nlay < 1 || nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
+    if (info->wlev != 0 && info->wlev != kWavLvl) return fail(WR_ERR_ARG, "wlev must be 0 or 4");
     if (verbose()) printf("Range decoding...\n");
     for (int l = 0; l < nlay; l++) if (int rc = ensure_host_plane(c, l, pitch)) return rc;
 
     size_t off[WR_NLAYMAX + 1] = {0};
     for (int l = 0; l < nlay; l++) off[l + 1] = off[l] + info->len_enc_vec[l];
     if (off[nlay] > info->ntot_enc) return fail(WR_ERR_STREAM, "len_enc_vec exceeds ntot_enc");
+    if (data_len && info->ntot_enc > data_len) return fail(WR_ERR_STREAM, "ntot_enc exceeds the length of the coded buffer");
+
+    SlotNeed need;
+    transform_need(nx, ny, nz, info->wlev ? -kWavLvl : 0, &need);
+    if (fld.host) need.field_elems = n;
+    need.planes_bytes = pitch * WR_NLAYMAX;
+
     size_t got[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
-    std::vector<std::thread> workers;
+    int up_err[WR_NLAYMAX] = {0};
     Sem sem(coder_threads());
+    const int dev = c->device;
     // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved
     const int groups = std::min(nlay, coder_threads());
-    for (int g = 0; g < groups; g++)
-        workers.emplace_back([&, g]() {
-            const int l0 = g * nlay / groups, l1 = (g + 1) * nlay / groups;
-            sem.acquire();
-            const double t = now();
-            const uint8_t* ins[WR_NLAYMAX];
-            uint8_t* syms[WR_NLAYMAX];
-            for (int l = l0; l < l1; l++) { ins[l - l0] = data_enc + off[l]; syms[l - l0] = c->h_plane[l]; }
-            wrrc::decode_planes(l1 - l0, ins, info->len_enc_vec + l0, syms, n, got + l0);
-            for (int l = l0; l < l1; l++) coder_s[l] = now() - t;
-            sem.release();
-        });
-    for (auto& w : workers) w.join();
-    int bad = -1;
-    for (int l = 0; l < nlay; l++) {
-        if (got[l] != n) bad = l;
-        if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
-    }
-    if (bad >= 0)
-        return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
-    const double t_coded = now();
-    if (verbose()) {  // wrappers.cpp:489, 503-510
-        for (int l = 0; l < nlay; l++) {
-            const uint8_t* q = c->h_plane[l];
-            unsigned lo = q[0], hi = q[0];
-            for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-            printf("ilay=%d\nimin=%u imax=%u med=%g\n", l, lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l]);
+    int rc = WR_OK;
+    double t_phase = 0, t_coded = 0;
+    try {
+        SlotLease slot;
+        // With a thread per plane the planes finish at different times (a leading plane of a smooth field
+        // decodes 2-3 times faster than a noise plane): if a slot is free right now, take it and let every
+        // thread upload its plane the moment it is decoded, while the later planes are still being decoded;
+        // the accumulate kernel then consumes them in plane order (wrappers.cpp:492-516 reorganised).  With
+        // grouped threads all planes of a group finish together, and the slot is only claimed afterwards.
+        const bool early = groups == nlay && nlay > 1 && slot.acquire(c, need, /*nowait=*/true, /*spare=*/1) == WR_OK;
+        if (early) g_stat[WR_STAT_EARLY_DECODES]++;
+        {
+            Workers workers;
+            for (int g = 0; g < groups; g++)
+                workers.v.emplace_back([&, g]() {
+                    const int l0 = g * nlay / groups, l1 = (g + 1) * nlay / groups;
+                    sem.acquire();
+                    const double t = now();
+                    const uint8_t* ins[WR_NLAYMAX];
+                    uint8_t* syms[WR_NLAYMAX];
+                    for (int l = l0; l < l1; l++) { ins[l - l0] = data_enc + off[l]; syms[l - l0] = c->h_plane[l]; }
+                    wrrc::decode_planes(l1 - l0, ins, info->len_enc_vec + l0, syms, n, got + l0);
+                    for (int l = l0; l < l1; l++) coder_s[l] = now() - t;
+                    sem.release();
+                    if (early) {
+                        (void)hipSetDevice(dev);
+                        StageLock up(pool->up_mu);
+                        for (int l = l0; l < l1; l++) {
+                            if (got[l] != n) continue;
+                            if (hipMemcpyAsync(slot->planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, pool->up) != hipSuccess ||
+                                hipEventRecord(c->ev_copy[l], pool->up) != hipSuccess)
+                                up_err[l] = 1;
+                        }
+                    }
+                });
         }
-        printf("Wavelet reconstruction...\n");
-    }
-    wrk::DequantParams p;
-    memset(&p, 0, sizeof p);
-    p.nlay = nlay;
-    for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; }
-    double t_phase = 0;
-    {
-        PhaseLock gpu(c->pool->phase);
-        t_phase = now();
-        if (int rc = ensure_planes(c, pitch * nlay)) return rc;
-        if (int rc = ensure_scratch(c, n)) return rc;
-        for (int l = 0; l < nlay; l++) p.q[l] = c->pool->planes + l * pitch;
-        for (int l = 0; l < nlay; l++)  // planes: pinned host -> device
-            HIPCHK(hipMemcpyAsync(c->pool->planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, c->stream));
-        if (int rc = inverse_from_planes(c, d_fld, nx, ny, nz, (int)info->wlev, p, &local)) return rc;
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        int bad = -1;
+        for (int l = 0; l < nlay; l++) {
+            if (got[l] != n) bad = l;
+            if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
+        }
+        if (bad >= 0) {
+            if (early) { StageLock up(pool->up_mu); (void)hipStreamSynchronize(pool->up); }
+            return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
+        }
+        t_coded = now();
+        if (verbose()) {  // wrappers.cpp:489, 503-510
+            for (int l = 0; l < nlay; l++) {
+                const uint8_t* q = c->h_plane[l];
+                unsigned lo = q[0], hi = q[0];
+                for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+                printf("ilay=%d\nimin=%u imax=%u med=%g\n", l, lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l]);
+            }
+            printf("Wavelet reconstruction...\n");
+        }
+        if (!early) {
+            if ((rc = slot.acquire(c, need)) != WR_OK) return rc;
+            t_phase = now();
+            // ---- stage "up": planes, pinned host -> device
+            StageLock up(pool->up_mu);
+            HIPCHK(hipEventRecord(c->ev_h2d0, pool->up));
+            for (int l = 0; l < nlay; l++) {
+                HIPCHK(hipMemcpyAsync(slot->planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, pool->up));
+                HIPCHK(hipEventRecord(c->ev_copy[l], pool->up));
+            }
+            HIPCHK(hipEventRecord(c->ev_h2d1, pool->up));
+        } else {
+            t_phase = t_coded;
+            for (int l = 0; l < nlay; l++)
+                if (up_err[l]) { StageLock up(pool->up_mu); (void)hipStreamSynchronize(pool->up); return fail(WR_ERR_HIP, "plane upload failed"); }
+        }
+        HIPCHK(hipEventSynchronize(c->ev_copy[nlay - 1]));
+        for (int l = 0; l + 1 < nlay; l++) HIPCHK(hipEventSynchronize(c->ev_copy[l]));  // early mode: uploads finish in any order
+        if (!early) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev_h2d0, c->ev_h2d1)); local.h2d_ms = ms; }
+        wrk::DequantParams p;
+        memset(&p, 0, sizeof p);
+        p.nlay = nlay;
+        for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = slot->planes + l * pitch; }
+        double* d_fld = fld.host ? slot->field : fld.dev;
+        {
+            // ---- stage "kernels"
+            StageLock cu(pool->cu_mu);
+            rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
+            if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
+            (void)hipStreamSynchronize(c->stream);
+        }
+        if (rc) return rc;
+        if (fld.host) {
+            // ---- stage "down": the reconstructed field, device -> host
+            {
+                StageLock down(pool->down_mu);
+                HIPCHK(hipEventRecord(c->ev_d2h0, pool->down));
+                HIPCHK(hipMemcpyAsync(fld.host, d_fld, n * sizeof(double), hipMemcpyDeviceToHost, pool->down));
+                HIPCHK(hipEventRecord(c->ev_d2h1, pool->down));
+            }
+            HIPCHK(hipEventSynchronize(c->ev_d2h1));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev_d2h0, c->ev_d2h1)); local.d2h_ms = ms;
+        }
+    } catch (const std::exception& e) {
+        return fail(WR_ERR_ARG, std::string("decode: ") + e.what());
     }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); local.quant_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_b, c->ev_c)); local.transform_ms = ms;
     local.total = now() - t0;
-    local.gpu = now() - t_phase;  // without the wait for the device
+    local.gpu = now() - t_phase;  // without the wait for a slot
     local.transfer = (t_coded - t0) - local.rangecoder;
     if (local.transfer < 0) local.transfer = 0;
     if (tm) *tm = local;
+    return WR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wr_encode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, double tolrel,
+                     wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm)
+{
+    Cutoff cut; cut.vec = &tolrel;
+    FieldRef f; f.dev = d_fld;
+    if (!d_fld) return fail(WR_ERR_ARG, "null device field pointer");
+    return encode_impl(c, f, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
+}
+
+int wr_encode_device_local(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int wtflag, int mx, int my, int mz,
+                           const double* cutoffvec, wr_enc_info* info, unsigned char* data_enc, size_t cap,
+                           wr_timings* tm)
+{
+    Cutoff cut; cut.mx = mx; cut.my = my; cut.mz = mz; cut.vec = cutoffvec;
+    FieldRef f; f.dev = d_fld;
+    if (!d_fld) return fail(WR_ERR_ARG, "null device field pointer");
+    return encode_impl(c, f, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
+}
+
+int wr_decode_device(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const wr_enc_info* info,
+                     const unsigned char* data_enc, size_t data_len, wr_timings* tm)
+{
+    FieldRef f; f.dev = d_fld;
+    if (!d_fld) return fail(WR_ERR_ARG, "null device field pointer");
+    return decode_impl(c, f, nx, ny, nz, info, data_enc, data_len, tm);
+}
+
+int wr_encode_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int wtflag, int mx, int my, int mz,
+                   const double* cutoffvec, wr_enc_info* info, unsigned char* data_enc, size_t cap, wr_timings* tm)
+{
+    Cutoff cut; cut.mx = mx; cut.my = my; cut.mz = mz; cut.vec = cutoffvec;
+    FieldRef f; f.host = h_fld;
+    return encode_impl(c, f, nx, ny, nz, wtflag, cut, info, data_enc, cap, tm);
+}
+
+int wr_decode_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, const wr_enc_info* info,
+                   const unsigned char* data_enc, size_t data_len, wr_timings* tm)
+{
+    FieldRef f; f.host = h_fld;
+    return decode_impl(c, f, nx, ny, nz, info, data_enc, data_len, tm);
+}
+
+int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (int rc = check_dims(nx, ny, nz, nullptr)) return rc;
+    if (!h_fld) return fail(WR_ERR_ARG, "null field pointer");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t n = (size_t)nx * ny * nz;
+    SlotNeed need;
+    transform_need(nx, ny, nz, lvl, &need);
+    need.field_elems = n;
+    SlotLease slot;
+    if (int rc = slot.acquire(c, need)) return rc;
+    DevPool* const pool = c->pool;
+    {
+        StageLock up(pool->up_mu);
+        HIPCHK(hipMemcpyAsync(slot->field, h_fld, n * sizeof(double), hipMemcpyHostToDevice, pool->up));
+        HIPCHK(hipEventRecord(c->ev_h2d1, pool->up));
+    }
+    HIPCHK(hipEventSynchronize(c->ev_h2d1));
+    double* res = nullptr;
+    {
+        StageLock cu(pool->cu_mu);
+        run_transform(c, slot.get(), slot->field, nx, ny, nz, lvl, &res);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    {
+        StageLock down(pool->down_mu);
+        HIPCHK(hipMemcpyAsync(h_fld, res, n * sizeof(double), hipMemcpyDeviceToHost, pool->down));
+        HIPCHK(hipEventRecord(c->ev_d2h1, pool->down));
+    }
+    HIPCHK(hipEventSynchronize(c->ev_d2h1));
     return WR_OK;
 }
 
@@ -929,12 +1299,14 @@ int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl
     if (int rc = ctx_bind(c)) return rc;
     if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
     if (reps < 1) return fail(WR_ERR_ARG, "reps < 1");
-    PhaseLock ph(c->pool->phase);
-    if (int rc = ensure_scratch(c, (size_t)nx * ny * nz)) return rc;
-    double* coef = nullptr;
+    SlotNeed need;
+    transform_need(nx, ny, nz, lvl, &need);
+    SlotLease slot;
+    if (int rc = slot.acquire(c, need)) return rc;
+    StageLock cu(c->pool->cu_mu);
+    double* res = nullptr;
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    for (int r = 0; r < reps; r++)
-        if (int rc = forward_transform(c, d_fld, nx, ny, nz, lvl, &coef)) return rc;  // fused: result stays in scratch
+    for (int r = 0; r < reps; r++) run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res);  // fused: result stays in scratch
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventSynchronize(c->ev_b));
@@ -951,8 +1323,11 @@ int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl
 // =====================================================================================
 namespace {
 
-wr_ctx* g_ctx = nullptr;
-std::mutex g_ctx_mu;
+// The reference's entry points are re-entrant on distinct buffers (wrappers.cpp works on locals only).
+// Here every call borrows a context from a free list (created on demand, kept for reuse), so concurrent
+// callers never share staging; their device stages serialise on the per-GPU stage locks.
+std::mutex g_free_mu;
+std::vector<wr_ctx*> g_free_ctx;
 
 [[noreturn]] void fatal(const char* where)
 {
@@ -960,16 +1335,26 @@ std::mutex g_ctx_mu;
     abort();
 }
 
-wr_ctx* default_ctx()
-{
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (!g_ctx) {
-        int dev = 0;
-        if (const char* e = getenv("WR_DEVICE")) dev = atoi(e);
-        if (wr_ctx_create(&g_ctx, dev, nullptr) != WR_OK) fatal("no GPU context");
+struct ImplicitCtx {
+    wr_ctx* c = nullptr;
+    explicit ImplicitCtx(const char* where)
+    {
+        {
+            std::lock_guard<std::mutex> lk(g_free_mu);
+            if (!g_free_ctx.empty()) { c = g_free_ctx.back(); g_free_ctx.pop_back(); }
+        }
+        if (!c) {
+            int dev = 0;
+            if (const char* e = getenv("WR_DEVICE")) dev = atoi(e);
+            if (wr_ctx_create(&c, dev, nullptr) != WR_OK) fatal(where);
+        }
     }
-    return g_ctx;
-}
+    ~ImplicitCtx()
+    {
+        std::lock_guard<std::mutex> lk(g_free_mu);
+        g_free_ctx.push_back(c);
+    }
+};
 
 }  // namespace
 
@@ -988,17 +1373,13 @@ void encoding_wrap(int nx, int ny, int nz, double* fld_1d, int wtflag, int mx, i
                    unsigned char* data_enc)
 {
     if (mx < 1 || my < 1 || mz < 1) { g_err = "mx, my, mz must be >= 1"; fatal("encoding_wrap"); }
-    wr_ctx* c = default_ctx();
-    const size_t n = (size_t)nx * ny * nz;
+    ImplicitCtx ic("encoding_wrap");
     unsigned char nl; unsigned long cap;
     setup_wr(nx, ny, nz, &nl, &cap);
-    if (ctx_bind(c) || ensure_field(c, n) || wr_dev_upload(c, c->d_field, fld_1d, n * sizeof(double))) fatal("encoding_wrap");
     wr_enc_info info;
-    const bool wb = getenv("WR_WRITEBACK_RESIDUAL") && atoi(getenv("WR_WRITEBACK_RESIDUAL"));
-    c->keep_residual = wb;
-    if (wr_encode_device_local(c, c->d_field, nx, ny, nz, wtflag, mx, my, mz, cutoffvec, &info, data_enc, cap, nullptr))
+    ic.c->keep_residual = writeback_residual() != 0;  // fld_1d ends up holding the residual (wrappers.cpp:397-398)
+    if (wr_encode_host(ic.c, fld_1d, nx, ny, nz, wtflag, mx, my, mz, cutoffvec, &info, data_enc, cap, nullptr))
         fatal("encoding_wrap");
-    if (wb && info.nlay && wr_dev_download(c, fld_1d, c->d_field, n * sizeof(double))) fatal("encoding_wrap");
     *tolabs = info.tolabs; *midval = info.midval; *halfspanval = info.halfspanval;
     *wlev = info.wlev; *nlay = info.nlay; *ntot_enc = info.ntot_enc;
     for (int l = 0; l < info.nlay; l++) {
@@ -1013,8 +1394,7 @@ void decoding_wrap(int nx, int ny, int nz, double* fld_1d, double* tolabs, doubl
                    double* minval_vec, unsigned long* len_enc_vec, unsigned char* data_enc)
 {
     (void)tolabs; (void)halfspanval;  // unused by the reference too (wrappers.h:62-64)
-    wr_ctx* c = default_ctx();
-    const size_t n = (size_t)nx * ny * nz;
+    ImplicitCtx ic("decoding_wrap");
     wr_enc_info info;
     memset(&info, 0, sizeof info);
     info.midval = *midval; info.wlev = *wlev; info.nlay = *nlay; info.ntot_enc = *ntot_enc;
@@ -1024,9 +1404,7 @@ void decoding_wrap(int nx, int ny, int nz, double* fld_1d, double* tolabs, doubl
         info.minval_vec[l] = minval_vec[l];
         info.len_enc_vec[l] = len_enc_vec[l];
     }
-    if (ctx_bind(c) || ensure_field(c, n)) fatal("decoding_wrap");
-    if (wr_decode_device(c, c->d_field, nx, ny, nz, &info, data_enc, nullptr)) fatal("decoding_wrap");
-    if (wr_dev_download(c, fld_1d, c->d_field, n * sizeof(double))) fatal("decoding_wrap");
+    if (wr_decode_host(ic.c, fld_1d, nx, ny, nz, &info, data_enc, 0, nullptr)) fatal("decoding_wrap");
 }
 
 void setup_wr_f(int* nx, int* ny, int* nz, int* nlaymax, long* ntot_enc_max)
@@ -1060,11 +1438,8 @@ void decoding_wrap_f(int* nx, int* ny, int* nz, double* fld, double* midval, dou
 
 void waveletcdf97_3d(int n1, int n2, int n3, int lvl, double* x)
 {
-    wr_ctx* c = default_ctx();
-    const size_t n = (size_t)n1 * n2 * n3;
-    if (ctx_bind(c) || ensure_field(c, n) || wr_dev_upload(c, c->d_field, x, n * sizeof(double)) ||
-        wr_dev_transform(c, c->d_field, n1, n2, n3, lvl) || wr_dev_download(c, x, c->d_field, n * sizeof(double)))
-        fatal("waveletcdf97_3d");
+    ImplicitCtx ic("waveletcdf97_3d");
+    if (wr_transform_host(ic.c, x, n1, n2, n3, lvl)) fatal("waveletcdf97_3d");
 }
 
 }  // extern "C"

@@ -130,14 +130,16 @@ __global__ __launch_bounds__(256) void k_line_x(double* __restrict__ X, int n, i
 // =====================================================================================
 template <bool INV>
 __global__ __launch_bounds__(64) void k_stream(const double* __restrict__ src, double* __restrict__ dst,
-                                               int n, size_t sa, int n1, size_t sb)
+                                               int n, size_t sa, int n1, size_t st, int nb, size_t sb)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n1) return;
-    const size_t base = (size_t)x + (size_t)blockIdx.y * sb;
+    const int m = (n + 1) >> 1;
+    // batch index b: a grid-stride loop, so that nb is not bound by the 65535 limit of gridDim.y
+    for (int b = blockIdx.y; b < nb; b += gridDim.y) {
+    const size_t base = (size_t)x * st + (size_t)b * sb;
     const double* in = src + base;
     double* out = dst + base;
-    const int m = (n + 1) >> 1;
 
     if (!INV) {
         double sr1 = 0, dr1 = 0, p1 = 0, q1 = 0, p2 = 0;
@@ -201,17 +203,30 @@ __global__ __launch_bounds__(64) void k_stream(const double* __restrict__ src, d
             lo = lo_nx; hi = hi_nx;
         }
     }
+    }
 }
 
 // box copy src -> dst (only needed when exactly one of the y/z passes was skipped)
-__global__ void k_copy_box(const double* __restrict__ src, double* __restrict__ dst, int n1, size_t sy,
-                           size_t sz)
+__global__ void k_copy_box(const double* __restrict__ src, double* __restrict__ dst, int n1, int n2, int n3,
+                           size_t sy, size_t sz)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n1) return;
-    size_t o = (size_t)x + (size_t)blockIdx.y * sy + (size_t)blockIdx.z * sz;
-    dst[o] = src[o];
+    for (int z = blockIdx.z; z < n3; z += gridDim.z)
+        for (int y = blockIdx.y; y < n2; y += gridDim.y) {
+            size_t o = (size_t)x + (size_t)y * sy + (size_t)z * sz;
+            dst[o] = src[o];
+        }
 }
+
+static inline unsigned grid_cap(int n) { return (unsigned)(n < 65535 ? n : 65535); }
+static void launch_copy_box(const double* src, double* dst, int n1, int n2, int n3, size_t sy, size_t sz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_box, dim3(cdiv(n1, 64), grid_cap(n2), grid_cap(n3)), dim3(64), 0, st, src, dst, n1, n2, n3, sy, sz);
+}
+
+// longest line the LDS-staged x pass takes (two half-lines of doubles + padding in 160 KiB)
+constexpr int kMaxLdsLine = 10200;
 
 static void launch_line_x(bool inv, double* X, int n, int n2, int n3, size_t sy, size_t sz, hipStream_t st)
 {
@@ -235,17 +250,20 @@ static void launch_line_x(bool inv, double* X, int n, int n2, int n3, size_t sy,
     }
 }
 
-// one y- or z-pass over the box (n1 x n2 x n3): axis 1 = y, 2 = z
+// one streaming pass over the box (n1 x n2 x n3): axis 1 = y, 2 = z (threads along x, coalesced);
+// axis 0 = x for lines too long for the LDS-staged kernel (threads along y: slow, but any length)
 static void launch_stream(bool inv, const double* src, double* dst, int axis, int n1, int n2, int n3,
                           size_t sy, size_t sz, hipStream_t st)
 {
-    const int n = axis == 1 ? n2 : n3;
-    const int nb = axis == 1 ? n3 : n2;
-    const size_t sa = axis == 1 ? sy : sz;
-    const size_t sb = axis == 1 ? sz : sy;
-    dim3 grid(cdiv(n1, 64), nb);
-    if (inv) hipLaunchKernelGGL(k_stream<true>, grid, dim3(64), 0, st, src, dst, n, sa, n1, sb);
-    else hipLaunchKernelGGL(k_stream<false>, grid, dim3(64), 0, st, src, dst, n, sa, n1, sb);
+    const int n = axis == 0 ? n1 : axis == 1 ? n2 : n3;          // marching axis
+    const int nt = axis == 0 ? n2 : n1;                           // threads
+    const int nb = axis == 1 ? n3 : axis == 2 ? n2 : n3;          // batches
+    const size_t sa = axis == 0 ? 1 : axis == 1 ? sy : sz;
+    const size_t tstride = axis == 0 ? sy : 1;
+    const size_t sb = axis == 2 ? sy : sz;
+    dim3 grid(cdiv(nt, 64), grid_cap(nb));
+    if (inv) hipLaunchKernelGGL(k_stream<true>, grid, dim3(64), 0, st, src, dst, n, sa, nt, tstride, nb, sb);
+    else hipLaunchKernelGGL(k_stream<false>, grid, dim3(64), 0, st, src, dst, n, sa, nt, tstride, nb, sb);
 }
 
 void transform(double* fld, double* scratch, int nx, int ny, int nz, int lvl, hipStream_t st)
@@ -268,21 +286,24 @@ void transform_level(double* fld, double* scratch, int nx, int ny, int nz, int k
             launch_stream(lvl < 0, cur, oth, axis, n1, n2, n3, sy, sz, st);
             double* t = cur; cur = oth; oth = t;
         };
+        const bool long_x = n1 > kMaxLdsLine;
         if (lvl >= 0) {
-            if (n1 > 1) launch_line_x(false, cur, n1, n2, n3, sy, sz, st);
+            if (n1 > 1) { if (long_x) stream_pass(0); else launch_line_x(false, cur, n1, n2, n3, sy, sz, st); }
             if (n2 > 1) stream_pass(1);
             if (n3 > 1) stream_pass(2);
         } else {
             if (n3 > 1) stream_pass(2);
             if (n2 > 1) stream_pass(1);
-            if (cur != fld) {  // bring the box home before the in-place x pass
-                hipLaunchKernelGGL(k_copy_box, dim3(cdiv(n1, 64), n2, n3), dim3(64), 0, st, cur, fld, n1, sy, sz);
-                cur = fld;
+            if (n1 > 1 && long_x) stream_pass(0);
+            else {
+                if (cur != fld) {  // bring the box home before the in-place x pass
+                    launch_copy_box(cur, fld, n1, n2, n3, sy, sz, st);
+                    cur = fld;
+                }
+                if (n1 > 1) launch_line_x(true, cur, n1, n2, n3, sy, sz, st);
             }
-            if (n1 > 1) launch_line_x(true, cur, n1, n2, n3, sy, sz, st);
         }
-        if (cur != fld)
-            hipLaunchKernelGGL(k_copy_box, dim3(cdiv(n1, 64), n2, n3), dim3(64), 0, st, cur, fld, n1, sy, sz);
+        if (cur != fld) launch_copy_box(cur, fld, n1, n2, n3, sy, sz, st);
     }
 }
 

@@ -132,3 +132,63 @@ def wrenc_sharded(in_path, wrb_path, wrh_path, specs, file_type, flip, codec, di
         write_container(wrh_path, wrb_path, os.path.basename(wrb_path), specs, file_type, flip, records)
     if dist is not None and world > 1:
         dist.barrier()
+
+
+def gpu_codec(device):
+    """The product codec for wrenc_sharded: wr_encode_host on this rank's GPU (field and coded bytes in host
+    memory, exactly what the drop-in encoding_wrap runs)."""
+    from . import api
+    ctx = api.Context(device)
+
+    def codec(fld, tol):
+        enc, _ = ctx.encode_host(np.ascontiguousarray(fld, dtype=np.float64), tol)
+        enc["data"] = enc["data"].copy()
+        return enc
+
+    codec.close = ctx.close
+    return codec
+
+
+def main(argv=None):
+    """Sharded generic encoder, one process per GPU:
+
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+            -m waverange_amd.sharded IN OUT HDR TYPE ENDIANFLIP NF PRECISION NX NY NZ TOL
+
+    (the generic wrenc command line, reference src/generic/gen_enc.cpp:365-412; every field has the same
+    shape and tolerance in this mode).  Rank r codes fields r, r + N, ... on GPU LOCAL_RANK (modulo the
+    visible GPUs); rank 0 gathers the coded fields over gloo -- host bytes, no GPU tensors travel -- and
+    writes the .wrh / .wrb pair in field order.  Without a launcher it runs as a single process."""
+    import os
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) != 11:
+        sys.stderr.write(main.__doc__ + "\n")
+        return 2
+    in_path, wrb_path, wrh_path = argv[0], argv[1], argv[2]
+    file_type, flip, nf, prec = int(argv[3]), int(argv[4]), int(argv[5]), int(argv[6])
+    nx, ny, nz, tol = int(argv[7]), int(argv[8]), int(argv[9]), float(argv[10])
+    specs = [dict(nbytes=4 if prec == 1 else 8, nx=nx, ny=ny, nz=nz, nh=1, idinv=0, icomp=1, tol_base=tol) for _ in range(nf)]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    from . import api
+    api.set_verbosity(0)
+    ndev = api.device_count()
+    if ndev < 1:
+        raise SystemExit("waverange_amd.sharded: no GPU visible (libwaverange_amd has no CPU fallback)")
+    codec = gpu_codec(local_rank % ndev)
+    try:
+        wrenc_sharded(in_path, wrb_path, wrh_path, specs, file_type, bool(flip), codec, dist)
+    finally:
+        codec.close()
+        if dist is not None:
+            dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
