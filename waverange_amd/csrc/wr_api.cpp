@@ -1159,9 +1159,12 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             for (int l = 0; l < nlay; l++)
                 if (up_err[l]) { StageLock up(pool->up_mu); (void)hipStreamSynchronize(pool->up); return fail(WR_ERR_HIP, "plane upload failed"); }
         }
-        HIPCHK(hipEventSynchronize(c->ev_copy[nlay - 1]));
-        for (int l = 0; l + 1 < nlay; l++) HIPCHK(hipEventSynchronize(c->ev_copy[l]));  // early mode: uploads finish in any order
-        if (!early) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev_h2d0, c->ev_h2d1)); local.h2d_ms = ms; }
+        for (int l = 0; l < nlay; l++) HIPCHK(hipEventSynchronize(c->ev_copy[l]));  // early mode: the threads queued them in any order
+        if (!early) {
+            float ms = 0;
+            HIPCHK(hipEventSynchronize(c->ev_h2d1));
+            HIPCHK(hipEventElapsedTime(&ms, c->ev_h2d0, c->ev_h2d1)); local.h2d_ms = ms;
+        }
         wrk::DequantParams p;
         memset(&p, 0, sizeof p);
         p.nlay = nlay;
