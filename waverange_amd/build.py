@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libwaverange_amd.so")
 ALIAS = os.path.join(HERE, "libwaverange.so")  # the reference's library name (drop-in link target)
 BIN = os.path.join(HERE, "bin")
 
-SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_rangecoder.cpp", "wr_compat.cpp"]
+SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_dma.cpp", "wr_rangecoder.cpp", "wr_compat.cpp"]
 CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"],
        # MSSG front-end (GrADS regular output, restart sets united / divided)
        "wrenc_mssg": ["cli/mssg_enc.cpp", "cli/mssg_io.cpp"], "wrdec_mssg": ["cli/mssg_dec.cpp", "cli/mssg_io.cpp"]}
@@ -60,7 +60,7 @@ def build(force=False, verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lhsa-runtime64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

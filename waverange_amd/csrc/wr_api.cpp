@@ -3,14 +3,16 @@
 // Mirrors the reference's codec layer (src/core/wrappers.cpp) for the path
 //   encoding_wrap : min/max -> forward transform -> bit-plane quantizer loop -> range coder
 //   decoding_wrap : range decoder -> dequantise-accumulate -> inverse transform
-// A call moves through three device stages, each with its own lock and (for the copies) its own
-// per-device stream, on one of a few work-space SLOTS per GPU:
-//   up      host -> device   field (encode) or quantized planes (decode)       stream DevPool::up
-//   kernels min/max, transform, quantizer / dequantizer                         the context's stream
-//   down    device -> host   planes + block histograms (encode) or field       stream DevPool::down
+// A call moves through three device stages on one of a few work-space SLOTS per GPU:
+//   up      host -> device   field (encode) or quantized planes (decode)       SDMA engine (wr_dma.h)
+//   kernels min/max, transform, quantizer / dequantizer                         the context's stream, one call
+//                                                                               at a time (DevPool::cu_mu)
+//   down    device -> host   planes + block histograms (encode) or field       SDMA engine
 // so that field k+1's upload and transform run under field k's plane download, and the host range
 // coder (one thread per plane, or fewer with the planes of a field interleaved in one loop:
-// wr_set_threads) starts on plane l the moment it is on the host.  Compiled with hipcc, strict IEEE
+// wr_set_threads) starts on plane l the moment it is on the host.  Copies and kernels are ordered from
+// the host (HIP event of the producing kernel -> start the copy; signal of the copy -> launch the
+// consumer); pageable caller memory goes through hipMemcpyAsync on a copy stream instead.  Compiled with hipcc, strict IEEE
 // (-ffp-contract=off): the scalar arithmetic on deps/aopt/bopt/tolabs below must round exactly as
 // wrappers.cpp:292-340 does.
 #include <float.h>
@@ -31,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/waverange_amd.h"
+#include "wr_dma.h"
 #include "wr_kernels.h"
 #include "wr_rangecoder.h"
 
@@ -135,8 +138,13 @@ struct DevPool {
     Slot slots[kMaxSlots];
     int max_slots = 3;
     int users = 0;
-    hipStream_t up = nullptr, down = nullptr;
+    hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
+    // clock keeper (wrk::keep_warm): resident while any call is between its upload and the end of its kernels
+    hipStream_t warm = nullptr;
+    unsigned int* warm_gen = nullptr;  // pinned host, device-visible
+    int warm_users = 0;
+    std::mutex warm_mu;
 };
 
 struct wr_ctx {
@@ -155,9 +163,18 @@ struct wr_ctx {
     uint16_t* h_hist = nullptr; size_t h_hist_elems = 0;  // pinned: per-block byte histograms, all planes
     // host coded-stream staging, one per plane
     uint8_t* enc_buf[WR_NLAYMAX] = {nullptr}; size_t enc_buf_bytes[WR_NLAYMAX] = {0};  // malloc'd: only coded bytes get touched
-    hipEvent_t ev_plane[WR_NLAYMAX] = {nullptr}, ev_copy[WR_NLAYMAX] = {nullptr};
+    hipEvent_t ev_plane[WR_NLAYMAX] = {nullptr};
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_mm = nullptr;
-    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    // A host <-> device transfer in flight: on a DMA engine through ROCr (signal) and / or, for pageable host
+    // memory, staged by the HIP runtime on the device's copy stream of that direction (event).
+    struct Xfer {
+        wrdma::Signal sig = 0;
+        hipEvent_t ev = nullptr;
+        bool dma_pending = false, hip_pending = false;
+        double t_start = 0, ms = 0;  // duration: engine timestamps of the last DMA copy, else host clock
+        std::mutex mu;               // several threads may wait for the same transfer
+    };
+    Xfer x_field, x_plane[WR_NLAYMAX];
     std::mutex mu;
 };
 
@@ -303,6 +320,97 @@ int ensure_host_hist(wr_ctx* c, size_t elems)
     c->h_hist_elems = elems;
     return WR_OK;
 }
+
+enum Dir { kUp = 0, kDown = 1 };
+struct Piece { void* dst; const void* src; size_t bytes; };
+
+bool dma_enabled()
+{
+    static const bool on = !(getenv("WR_NO_DMA") && atoi(getenv("WR_NO_DMA")));
+    return on;
+}
+
+// Starts the pieces of one transfer: on a DMA engine where ROCr knows the host memory (pinned), through
+// hipMemcpyAsync on the device's copy stream of that direction otherwise.  Never blocks on the copies.
+int xfer_start(wr_ctx* c, wr_ctx::Xfer* x, const Piece* pc, int count, Dir dir)
+{
+    bool able[4] = {false, false, false, false};
+    int ndma = 0;
+    const bool use = x->sig && dma_enabled();
+    for (int k = 0; k < count; k++) { able[k] = use && wrdma::can_copy(pc[k].dst, pc[k].src); ndma += able[k]; }
+    std::lock_guard<std::mutex> lk(x->mu);
+    x->t_start = now();
+    x->ms = 0;
+    if (ndma) {
+        wrdma::signal_arm(x->sig, ndma);
+        x->dma_pending = true;
+        int started = 0;
+        for (int k = 0; k < count; k++) {
+            if (!able[k]) continue;
+            if (wrdma::copy_async(pc[k].dst, pc[k].src, pc[k].bytes, x->sig) != 0) {
+                wrdma::signal_cancel(x->sig, ndma - started);
+                return fail(WR_ERR_HIP, "DMA copy could not be queued");
+            }
+            started++;
+        }
+    }
+    if (ndma < count) {
+        DevPool* p = c->pool;
+        hipStream_t st = dir == kUp ? p->up : p->down;
+        StageLock lk(dir == kUp ? p->up_mu : p->down_mu);
+        for (int k = 0; k < count; k++)
+            if (!able[k])
+                HIPCHK(hipMemcpyAsync(pc[k].dst, pc[k].src, pc[k].bytes, dir == kUp ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(x->ev, st));
+        x->hip_pending = true;
+    }
+    return WR_OK;
+}
+
+// Waits for a transfer (no-op if none is pending).  May be called from any thread, once per start.
+int xfer_wait(wr_ctx::Xfer* x)
+{
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = WR_OK;
+    const bool timed_by_host = x->hip_pending;
+    if (x->hip_pending) {
+        if (hipEventSynchronize(x->ev) != hipSuccess) rc = fail(WR_ERR_HIP, "copy failed");
+        x->hip_pending = false;
+    }
+    if (x->dma_pending) {
+        if (wrdma::wait(x->sig) != 0) rc = fail(WR_ERR_HIP, "DMA copy failed");
+        x->dma_pending = false;
+        const double ms = wrdma::last_copy_ms(x->sig);
+        x->ms = (!timed_by_host && ms >= 0) ? ms : (now() - x->t_start) * 1e3;
+    } else if (timed_by_host) {
+        x->ms = (now() - x->t_start) * 1e3;
+    }
+    return rc;
+}
+
+// Keeps one idle wave resident on the device from the start of a call's upload to the end of its kernels,
+// so that the kernels find the clocks up (wrk::keep_warm; WR_KEEP_WARM=0 turns it off).
+class WarmGuard {
+public:
+    explicit WarmGuard(wr_ctx* c) : p_(c->pool)
+    {
+        static const bool on = !(getenv("WR_KEEP_WARM") && !atoi(getenv("WR_KEEP_WARM")));
+        if (!on || !p_->warm || !p_->warm_gen) { p_ = nullptr; return; }
+        std::lock_guard<std::mutex> lk(p_->warm_mu);
+        if (p_->warm_users++ == 0) wrk::keep_warm(p_->warm_gen, *p_->warm_gen, 600.0, p_->warm);
+    }
+    ~WarmGuard() { done(); }
+    void done()
+    {
+        if (!p_) return;
+        std::lock_guard<std::mutex> lk(p_->warm_mu);
+        if (--p_->warm_users == 0) __atomic_add_fetch(p_->warm_gen, 1u, __ATOMIC_RELEASE);  // the keeper sees it and leaves
+        p_ = nullptr;
+    }
+
+private:
+    DevPool* p_;
+};
 
 bool use_fused(int nx, int ny, int nz, int lvl)
 {
@@ -488,6 +596,11 @@ static int ctx_init(wr_ctx* c, int device, void* hip_stream)
             HIPCHK(hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
         }
         if (!p->down) HIPCHK(hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
+        if (!p->warm) HIPCHK(hipStreamCreateWithFlags(&p->warm, hipStreamNonBlocking));
+        if (!p->warm_gen) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&p->warm_gen), 64, hipHostMallocDefault));
+            *p->warm_gen = 1;
+        }
     }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -497,13 +610,15 @@ static int ctx_init(wr_ctx* c, int device, void* hip_stream)
     HIPCHK(hipHostMalloc(&c->h_result, 8 * sizeof(double), hipHostMallocDefault));
     for (int i = 0; i < WR_NLAYMAX; i++) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_plane[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreate(&c->ev_a)); HIPCHK(hipEventCreate(&c->ev_b));
     HIPCHK(hipEventCreate(&c->ev_c)); HIPCHK(hipEventCreate(&c->ev_d));
     HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
-    HIPCHK(hipEventCreate(&c->ev_h2d0)); HIPCHK(hipEventCreate(&c->ev_h2d1));
-    HIPCHK(hipEventCreate(&c->ev_d2h0)); HIPCHK(hipEventCreate(&c->ev_d2h1));
+    for (wr_ctx::Xfer* x : {&c->x_field, &c->x_plane[0], &c->x_plane[1], &c->x_plane[2], &c->x_plane[3], &c->x_plane[4],
+                            &c->x_plane[5], &c->x_plane[6], &c->x_plane[7]}) {
+        x->sig = wrdma::signal_create();  // 0 if ROCr is not usable: every copy then goes through hipMemcpyAsync
+        HIPCHK(hipEventCreateWithFlags(&x->ev, hipEventDisableTiming));
+    }
     return WR_OK;
 }
 
@@ -548,10 +663,14 @@ void wr_ctx_destroy(wr_ctx* c)
     }
     for (int i = 0; i < WR_NLAYMAX; i++) {
         if (c->ev_plane[i]) (void)hipEventDestroy(c->ev_plane[i]);
-        if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
     }
-    for (hipEvent_t ev : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_mm, c->ev_h2d0, c->ev_h2d1, c->ev_d2h0, c->ev_d2h1})
+    for (hipEvent_t ev : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_mm})
         if (ev) (void)hipEventDestroy(ev);
+    for (wr_ctx::Xfer* x : {&c->x_field, &c->x_plane[0], &c->x_plane[1], &c->x_plane[2], &c->x_plane[3], &c->x_plane[4],
+                            &c->x_plane[5], &c->x_plane[6], &c->x_plane[7]}) {
+        wrdma::signal_destroy(x->sig);
+        if (x->ev) (void)hipEventDestroy(x->ev);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     {   // the last context on a device releases the shared work space
         std::lock_guard<std::mutex> lk(g_pools_mu);
@@ -560,6 +679,12 @@ void wr_ctx_destroy(wr_ctx* c)
             std::lock_guard<std::mutex> sl(p->mu);
             if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); p->up = nullptr; }
             if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); p->down = nullptr; }
+            if (p->warm) {
+                if (p->warm_gen) __atomic_add_fetch(p->warm_gen, 1u, __ATOMIC_RELEASE);
+                (void)hipStreamSynchronize(p->warm); (void)hipStreamDestroy(p->warm); p->warm = nullptr;
+            }
+            if (p->warm_gen) { (void)hipHostFree(p->warm_gen); p->warm_gen = nullptr; }
+            p->warm_users = 0;
             for (Slot& s : p->slots) s.release_buffers();
         }
     }
@@ -710,13 +835,15 @@ struct Cutoff {
     int count() const { return mx * my * mz; }
 };
 
-// Kernel stage of the encoder (call with the slot leased and DevPool::cu_mu held).  on_plane(l, last) is
-// called right after plane l's quantizer kernel and the read-back of the next plane's min/max have
-// been enqueued (the full pipeline hooks the histograms, the D2H and the coder thread in there).
-// *resid = where the coefficient array / residual lives afterwards.
-template <class OnPlane>
+// Kernel stage of the encoder (call with the slot leased and DevPool::cu_mu held).  Two hooks for the full
+// pipeline: after_quant(l) is called right after plane l's quantizer kernel and the read-back of the next
+// plane's min/max have been enqueued (the block histograms are enqueued there, behind the read-back);
+// plane_ready(l, last) is called from the host once everything enqueued for plane l has completed on the
+// device (the download starts there).  *resid = where the coefficient array / residual lives afterwards.
+template <class AfterQuant, class PlaneReady>
 int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
-                       uint8_t* d_planes, wr_enc_info* info, wr_timings* tm, OnPlane on_plane, double** resid)
+                       uint8_t* d_planes, wr_enc_info* info, wr_timings* tm, AfterQuant after_quant, PlaneReady plane_ready,
+                       double** resid)
 {
     // minimum cutoff = the global relative tolerance (wrappers.cpp:288-290)
     double tolrel = cut.vec[0];
@@ -783,15 +910,23 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
                             c->d_partial, c->d_result, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
         HIPCHK(hipGetLastError());
-        // the next plane's min/max goes to the host first; what on_plane enqueues runs behind it
+        // the next plane's min/max goes to the host first; what after_quant enqueues runs behind it
         if (!s.last)
             HIPCHK(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(c->ev_mm, c->stream));
-        if (int rc = on_plane(ilay, s.last)) return rc;
-        ilay++;
+        if (int rc = after_quant(ilay)) return rc;
+        HIPCHK(hipEventRecord(c->ev_plane[ilay], c->stream));
         HIPCHK(hipEventSynchronize(c->ev_mm));
         HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); quant_ms += ms;
-        if (s.last) break;
+        // plane ilay-1 is complete: what after_quant enqueued for it ran before this plane's quantizer
+        if (ilay > 0) if (int rc = plane_ready(ilay - 1, false)) return rc;
+        if (s.last) {
+            HIPCHK(hipEventSynchronize(c->ev_plane[ilay]));
+            if (int rc = plane_ready(ilay, true)) return rc;
+            ilay++;
+            break;
+        }
+        ilay++;
         lo = c->h_result[0]; hi = c->h_result[1];
         if (lo == 0.0)  // sign of a zero minimum: rare path, goes through the full read-back
             if (int rc = read_minmax(c, d_fld, n, true, &lo, &hi)) return rc;
@@ -820,7 +955,7 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     Cutoff cut; cut.vec = &tolrel;
     double* resid = nullptr;
     int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, d_planes, info, nullptr,
-                                [](unsigned, bool) { return WR_OK; }, &resid);
+                                [](unsigned) { return WR_OK; }, [](unsigned, bool) { return WR_OK; }, &resid);
     if (rc == WR_OK && resid != d_fld && info->nlay)  // d_fld holds the residual afterwards (header contract)
         if (hipMemcpyAsync(d_fld, resid, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             rc = fail(WR_ERR_HIP, "residual copy failed");
@@ -889,6 +1024,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
 
     size_t lens[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
+    int copy_failed[WR_NLAYMAX] = {0};
     std::string logs[WR_NLAYMAX];
     Sem sem(encoder_threads());
     const int dev = c->device;
@@ -900,7 +1036,8 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     const bool per_plane = encoder_threads() >= WR_NLAYMAX;
     auto code_group = [&](unsigned l0, unsigned l1) {
         (void)hipSetDevice(dev);
-        (void)hipEventSynchronize(c->ev_copy[l1 - 1]);  // copies complete in plane order
+        for (unsigned l = l0; l < l1; l++)
+            if (xfer_wait(&c->x_plane[l]) != WR_OK) copy_failed[l] = 1;
         sem.acquire();
         const double t = now();
         const uint8_t* syms[WR_NLAYMAX];
@@ -931,73 +1068,62 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
 
     int rc = WR_OK;
     double t_phase = 0, t_gpu_done = 0;
-    bool planes_in_flight = false;
+    unsigned planes_started = 0;
     try {
         SlotLease slot;
         if ((rc = slot.acquire(c, need)) != WR_OK) return rc;
         t_phase = now();
+        WarmGuard warm(c);
         double* d_fld = fld.dev;
         if (fld.host) {
-            // ---- stage "up": the field goes host -> device on the device's upload stream
+            // ---- stage "up": the field goes host -> device; the kernel stage is only claimed once it has
+            // arrived, so other calls compute meanwhile
             d_fld = slot->field;
-            {
-                StageLock up(pool->up_mu);
-                HIPCHK(hipEventRecord(c->ev_h2d0, pool->up));
-                HIPCHK(hipMemcpyAsync(d_fld, fld.host, n * sizeof(double), hipMemcpyHostToDevice, pool->up));
-                HIPCHK(hipEventRecord(c->ev_h2d1, pool->up));
-            }
-            HIPCHK(hipEventSynchronize(c->ev_h2d1));  // before the kernel stage is claimed: others may compute meanwhile
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev_h2d0, c->ev_h2d1)); local.h2d_ms = ms;
+            const Piece pc = {d_fld, fld.host, n * sizeof(double)};
+            if ((rc = xfer_start(c, &c->x_field, &pc, 1, kUp)) != WR_OK) return rc;
+            if ((rc = xfer_wait(&c->x_field)) != WR_OK) return rc;
+            local.h2d_ms = (float)c->x_field.ms;
         }
         double* resid = d_fld;
-        bool first_copy = true;
-        auto on_plane = [&](unsigned l, bool) -> int {
-            // histograms on the kernel stream (behind the min/max read-back), then plane l: device ->
-            // pinned host on the device's download stream, which never runs a kernel
+        auto after_quant = [&](unsigned l) -> int {
+            // block histograms of plane l on the kernel stream, behind the read-back of the next plane's min/max
             wrk::block_histograms(slot->planes + l * pitch, n, slot->hist + l * hist_per_plane, c->stream);
-            HIPCHK(hipEventRecord(c->ev_plane[l], c->stream));
+            return WR_OK;
+        };
+        auto plane_ready = [&](unsigned l, bool) -> int {
+            // plane l and its histograms are complete on the device: off they go to pinned host memory, and a
+            // coder thread waits for them
             if (int r = ensure_host_plane(c, (int)l, pitch)) return r;
             if (int r = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return r;
-            {
-                StageLock down(pool->down_mu);
-                HIPCHK(hipStreamWaitEvent(pool->down, c->ev_plane[l], 0));
-                if (first_copy) { HIPCHK(hipEventRecord(c->ev_d2h0, pool->down)); first_copy = false; }
-                HIPCHK(hipMemcpyAsync(c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t),
-                                      hipMemcpyDeviceToHost, pool->down));
-                HIPCHK(hipMemcpyAsync(c->h_plane[l], slot->planes + l * pitch, n, hipMemcpyDeviceToHost, pool->down));
-                HIPCHK(hipEventRecord(c->ev_copy[l], pool->down));
-            }
-            planes_in_flight = true;
+            const Piece pc[2] = {{c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t)},
+                                 {c->h_plane[l], slot->planes + l * pitch, n}};
+            if (int r = xfer_start(c, &c->x_plane[l], pc, 2, kDown)) return r;
+            planes_started = l + 1;
             if (per_plane) workers.v.emplace_back(code_group, l, l + 1);
             return WR_OK;
         };
         {
             // ---- stage "kernels"
             StageLock cu(pool->cu_mu);
-            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, slot->planes, info, &local, on_plane, &resid);
-            if (rc == WR_OK && info->nlay) (void)hipEventSynchronize(c->ev_plane[info->nlay - 1]);
-            else (void)hipStreamSynchronize(c->stream);
-        }
-        // ---- stage "down": the plane copies were queued as the planes appeared; the residual follows them
-        if (rc == WR_OK && info->nlay) {
-            if (c->keep_residual && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
-                HIPCHK(hipMemcpyAsync(fld.dev, resid, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
+            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, slot->planes, info, &local, after_quant, plane_ready, &resid);
+            (void)hipStreamSynchronize(c->stream);
+            if (rc == WR_OK && c->keep_residual && info->nlay && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
+                if (hipMemcpyAsync(fld.dev, resid, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess)
+                    rc = fail(WR_ERR_HIP, "residual copy failed");
             }
-            {
-                StageLock down(pool->down_mu);
-                if (c->keep_residual && fld.host)
-                    HIPCHK(hipMemcpyAsync(fld.host, resid, n * sizeof(double), hipMemcpyDeviceToHost, pool->down));
-                HIPCHK(hipEventRecord(c->ev_d2h1, pool->down));
-            }
-            HIPCHK(hipEventSynchronize(c->ev_d2h1));
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, c->ev_d2h0, c->ev_d2h1) == hipSuccess) local.d2h_ms = ms;
-        } else if (planes_in_flight) {
-            StageLock down(pool->down_mu);
-            (void)hipStreamSynchronize(pool->down);  // error path: nothing of this call may stay queued on the slot
         }
+        warm.done();
+        // ---- stage "down": the plane downloads were started as the planes completed; the residual follows them
+        if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
+            const Piece pc = {fld.host, resid, n * sizeof(double)};
+            if ((rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) == WR_OK) rc = xfer_wait(&c->x_field);
+        }
+        // The slot's plane buffers must not be reused before their downloads are done (the coder threads wait
+        // for the same transfers; xfer_wait is safe to call from both sides).
+        for (unsigned l = 0; l < planes_started; l++)
+            if (xfer_wait(&c->x_plane[l]) != WR_OK) copy_failed[l] = 1;
+        for (unsigned l = 0; l < planes_started; l++) local.d2h_ms += (float)c->x_plane[l].ms;
         t_gpu_done = now();
         // the slot goes back here: its planes are on the host
     } catch (const std::exception& e) {
@@ -1016,6 +1142,8 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     }
     workers.join();
     if (rc) return rc;
+    for (unsigned l = 0; l < info->nlay; l++)
+        if (copy_failed[l]) return fail(WR_ERR_HIP, "download of plane " + std::to_string(l) + " failed");
     const double t_coded = now();
     // concatenate the plane streams (wrappers.cpp:412-427); gigabytes at 1024^3, so one copier per plane
     size_t total = 0, offs[WR_NLAYMAX] = {0};
@@ -1093,12 +1221,17 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     try {
         SlotLease slot;
         // With a thread per plane the planes finish at different times (a leading plane of a smooth field
-        // decodes 2-3 times faster than a noise plane): if a slot is free right now, take it and let every
-        // thread upload its plane the moment it is decoded, while the later planes are still being decoded;
-        // the accumulate kernel then consumes them in plane order (wrappers.cpp:492-516 reorganised).  With
-        // grouped threads all planes of a group finish together, and the slot is only claimed afterwards.
+        // decodes 2-3 times faster than a noise plane): if a slot is free right now (and not the last one),
+        // take it and let every thread upload its plane the moment it is decoded, while the later planes
+        // are still being decoded; the accumulate kernel then consumes them in plane order
+        // (wrappers.cpp:492-516 reorganised).  With grouped threads all planes of a group finish together,
+        // and the slot is only claimed afterwards.
         const bool early = groups == nlay && nlay > 1 && slot.acquire(c, need, /*nowait=*/true, /*spare=*/1) == WR_OK;
         if (early) g_stat[WR_STAT_EARLY_DECODES]++;
+        auto upload_plane = [&](int l) -> int {
+            const Piece pc = {slot->planes + l * pitch, c->h_plane[l], n};
+            return xfer_start(c, &c->x_plane[l], &pc, 1, kUp);
+        };
         {
             Workers workers;
             for (int g = 0; g < groups; g++)
@@ -1114,13 +1247,8 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
                     sem.release();
                     if (early) {
                         (void)hipSetDevice(dev);
-                        StageLock up(pool->up_mu);
-                        for (int l = l0; l < l1; l++) {
-                            if (got[l] != n) continue;
-                            if (hipMemcpyAsync(slot->planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, pool->up) != hipSuccess ||
-                                hipEventRecord(c->ev_copy[l], pool->up) != hipSuccess)
-                                up_err[l] = 1;
-                        }
+                        for (int l = l0; l < l1; l++)
+                            if (got[l] == n && upload_plane(l) != WR_OK) up_err[l] = 1;
                     }
                 });
         }
@@ -1130,7 +1258,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
         }
         if (bad >= 0) {
-            if (early) { StageLock up(pool->up_mu); (void)hipStreamSynchronize(pool->up); }
+            if (early) for (int l = 0; l < nlay; l++) (void)xfer_wait(&c->x_plane[l]);
             return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
         }
         t_coded = now();
@@ -1146,25 +1274,19 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         if (!early) {
             if ((rc = slot.acquire(c, need)) != WR_OK) return rc;
             t_phase = now();
-            // ---- stage "up": planes, pinned host -> device
-            StageLock up(pool->up_mu);
-            HIPCHK(hipEventRecord(c->ev_h2d0, pool->up));
-            for (int l = 0; l < nlay; l++) {
-                HIPCHK(hipMemcpyAsync(slot->planes + l * pitch, c->h_plane[l], n, hipMemcpyHostToDevice, pool->up));
-                HIPCHK(hipEventRecord(c->ev_copy[l], pool->up));
-            }
-            HIPCHK(hipEventRecord(c->ev_h2d1, pool->up));
         } else {
             t_phase = t_coded;
+        }
+        WarmGuard warm(c);
+        if (!early)  // ---- stage "up": planes, pinned host -> device
             for (int l = 0; l < nlay; l++)
-                if (up_err[l]) { StageLock up(pool->up_mu); (void)hipStreamSynchronize(pool->up); return fail(WR_ERR_HIP, "plane upload failed"); }
+                if (upload_plane(l) != WR_OK) up_err[l] = 1;
+        for (int l = 0; l < nlay; l++) {
+            if (xfer_wait(&c->x_plane[l]) != WR_OK) up_err[l] = 1;
+            local.h2d_ms += (float)c->x_plane[l].ms;
         }
-        for (int l = 0; l < nlay; l++) HIPCHK(hipEventSynchronize(c->ev_copy[l]));  // early mode: the threads queued them in any order
-        if (!early) {
-            float ms = 0;
-            HIPCHK(hipEventSynchronize(c->ev_h2d1));
-            HIPCHK(hipEventElapsedTime(&ms, c->ev_h2d0, c->ev_h2d1)); local.h2d_ms = ms;
-        }
+        for (int l = 0; l < nlay; l++)
+            if (up_err[l]) return fail(WR_ERR_HIP, "upload of plane " + std::to_string(l) + " failed");
         wrk::DequantParams p;
         memset(&p, 0, sizeof p);
         p.nlay = nlay;
@@ -1177,18 +1299,14 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
             (void)hipStreamSynchronize(c->stream);
         }
+        warm.done();
         if (rc) return rc;
         if (fld.host) {
             // ---- stage "down": the reconstructed field, device -> host
-            {
-                StageLock down(pool->down_mu);
-                HIPCHK(hipEventRecord(c->ev_d2h0, pool->down));
-                HIPCHK(hipMemcpyAsync(fld.host, d_fld, n * sizeof(double), hipMemcpyDeviceToHost, pool->down));
-                HIPCHK(hipEventRecord(c->ev_d2h1, pool->down));
-            }
-            HIPCHK(hipEventSynchronize(c->ev_d2h1));
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev_d2h0, c->ev_d2h1)); local.d2h_ms = ms;
+            const Piece pc = {fld.host, d_fld, n * sizeof(double)};
+            if ((rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) != WR_OK) return rc;
+            if ((rc = xfer_wait(&c->x_field)) != WR_OK) return rc;
+            local.d2h_ms = (float)c->x_field.ms;
         }
     } catch (const std::exception& e) {
         return fail(WR_ERR_ARG, std::string("decode: ") + e.what());
@@ -1263,12 +1381,12 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
     SlotLease slot;
     if (int rc = slot.acquire(c, need)) return rc;
     DevPool* const pool = c->pool;
+    WarmGuard warm(c);
     {
-        StageLock up(pool->up_mu);
-        HIPCHK(hipMemcpyAsync(slot->field, h_fld, n * sizeof(double), hipMemcpyHostToDevice, pool->up));
-        HIPCHK(hipEventRecord(c->ev_h2d1, pool->up));
+        const Piece pc = {slot->field, h_fld, n * sizeof(double)};
+        if (int rc = xfer_start(c, &c->x_field, &pc, 1, kUp)) return rc;
+        if (int rc = xfer_wait(&c->x_field)) return rc;
     }
-    HIPCHK(hipEventSynchronize(c->ev_h2d1));
     double* res = nullptr;
     {
         StageLock cu(pool->cu_mu);
@@ -1276,13 +1394,10 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    {
-        StageLock down(pool->down_mu);
-        HIPCHK(hipMemcpyAsync(h_fld, res, n * sizeof(double), hipMemcpyDeviceToHost, pool->down));
-        HIPCHK(hipEventRecord(c->ev_d2h1, pool->down));
-    }
-    HIPCHK(hipEventSynchronize(c->ev_d2h1));
-    return WR_OK;
+    warm.done();
+    const Piece pc = {h_fld, res, n * sizeof(double)};
+    if (int rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) return rc;
+    return xfer_wait(&c->x_field);
 }
 
 size_t wr_range_encode_bound(size_t n) { return wrrc::encode_bound(n); }
