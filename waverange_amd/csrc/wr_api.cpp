@@ -140,11 +140,6 @@ struct DevPool {
     int users = 0;
     hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
-    // clock keeper (wrk::keep_warm): resident while any call is between its upload and the end of its kernels
-    hipStream_t warm = nullptr;
-    unsigned int* warm_gen = nullptr;  // pinned host, device-visible
-    int warm_users = 0;
-    std::mutex warm_mu;
 };
 
 struct wr_ctx {
@@ -388,30 +383,6 @@ int xfer_wait(wr_ctx::Xfer* x)
     return rc;
 }
 
-// Keeps one idle wave resident on the device from the start of a call's upload to the end of its kernels,
-// so that the kernels find the clocks up (wrk::keep_warm; WR_KEEP_WARM=0 turns it off).
-class WarmGuard {
-public:
-    explicit WarmGuard(wr_ctx* c) : p_(c->pool)
-    {
-        static const bool on = !(getenv("WR_KEEP_WARM") && !atoi(getenv("WR_KEEP_WARM")));
-        if (!on || !p_->warm || !p_->warm_gen) { p_ = nullptr; return; }
-        std::lock_guard<std::mutex> lk(p_->warm_mu);
-        if (p_->warm_users++ == 0) wrk::keep_warm(p_->warm_gen, *p_->warm_gen, 600.0, p_->warm);
-    }
-    ~WarmGuard() { done(); }
-    void done()
-    {
-        if (!p_) return;
-        std::lock_guard<std::mutex> lk(p_->warm_mu);
-        if (--p_->warm_users == 0) __atomic_add_fetch(p_->warm_gen, 1u, __ATOMIC_RELEASE);  // the keeper sees it and leaves
-        p_ = nullptr;
-    }
-
-private:
-    DevPool* p_;
-};
-
 bool use_fused(int nx, int ny, int nz, int lvl)
 {
     return wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED");
@@ -596,11 +567,6 @@ static int ctx_init(wr_ctx* c, int device, void* hip_stream)
             HIPCHK(hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
         }
         if (!p->down) HIPCHK(hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
-        if (!p->warm) HIPCHK(hipStreamCreateWithFlags(&p->warm, hipStreamNonBlocking));
-        if (!p->warm_gen) {
-            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&p->warm_gen), 64, hipHostMallocDefault));
-            *p->warm_gen = 1;
-        }
     }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -679,12 +645,6 @@ void wr_ctx_destroy(wr_ctx* c)
             std::lock_guard<std::mutex> sl(p->mu);
             if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); p->up = nullptr; }
             if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); p->down = nullptr; }
-            if (p->warm) {
-                if (p->warm_gen) __atomic_add_fetch(p->warm_gen, 1u, __ATOMIC_RELEASE);
-                (void)hipStreamSynchronize(p->warm); (void)hipStreamDestroy(p->warm); p->warm = nullptr;
-            }
-            if (p->warm_gen) { (void)hipHostFree(p->warm_gen); p->warm_gen = nullptr; }
-            p->warm_users = 0;
             for (Slot& s : p->slots) s.release_buffers();
         }
     }
@@ -1073,7 +1033,6 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         SlotLease slot;
         if ((rc = slot.acquire(c, need)) != WR_OK) return rc;
         t_phase = now();
-        WarmGuard warm(c);
         double* d_fld = fld.dev;
         if (fld.host) {
             // ---- stage "up": the field goes host -> device; the kernel stage is only claimed once it has
@@ -1113,7 +1072,6 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
                     rc = fail(WR_ERR_HIP, "residual copy failed");
             }
         }
-        warm.done();
         // ---- stage "down": the plane downloads were started as the planes completed; the residual follows them
         if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
             const Piece pc = {fld.host, resid, n * sizeof(double)};
@@ -1277,7 +1235,6 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         } else {
             t_phase = t_coded;
         }
-        WarmGuard warm(c);
         if (!early)  // ---- stage "up": planes, pinned host -> device
             for (int l = 0; l < nlay; l++)
                 if (upload_plane(l) != WR_OK) up_err[l] = 1;
@@ -1299,7 +1256,6 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
             (void)hipStreamSynchronize(c->stream);
         }
-        warm.done();
         if (rc) return rc;
         if (fld.host) {
             // ---- stage "down": the reconstructed field, device -> host
@@ -1381,7 +1337,6 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
     SlotLease slot;
     if (int rc = slot.acquire(c, need)) return rc;
     DevPool* const pool = c->pool;
-    WarmGuard warm(c);
     {
         const Piece pc = {slot->field, h_fld, n * sizeof(double)};
         if (int rc = xfer_start(c, &c->x_field, &pc, 1, kUp)) return rc;
@@ -1394,7 +1349,6 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    warm.done();
     const Piece pc = {h_fld, res, n * sizeof(double)};
     if (int rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) return rc;
     return xfer_wait(&c->x_field);

@@ -64,9 +64,6 @@ void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, i
 // per-60000-symbol-block byte histograms of a plane (feeds the host range coder's model):
 // hist[b*256 + v] = count of value v in block b (uint16, block size < 65536)
 void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st);
-// clock keeper: a single resident wave that idles until *gen != mine (gen: device-visible host memory) or
-// max_ms have passed
-void keep_warm(const unsigned int* gen, unsigned int mine, double max_ms, hipStream_t st);
 
 }  // namespace wrk
 

@@ -675,21 +675,6 @@ __global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, siz
     hist[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)tot;
 }
 
-// One wave that does nothing until *gen moves on from `mine` (or max_ticks of the 100 MHz wall clock pass:
-// the exit every launch reaches).  While it is resident the device counts as busy, so the power management
-// brings the clocks up during the PCIe upload that precedes a kernel stage (after an idle gap the first
-// ~35 ms of kernels otherwise run 10-25 % slow: profiles/r02/NOTES.md).
-__global__ void k_keep_warm(const volatile unsigned int* gen, unsigned int mine, unsigned long long max_ticks)
-{
-    const unsigned long long t0 = wall_clock64();
-    while (*gen == mine && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
-}
-
-void keep_warm(const unsigned int* gen, unsigned int mine, double max_ms, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_keep_warm, dim3(1), dim3(64), 0, st, gen, mine, (unsigned long long)(max_ms * 1e5));
-}
-
 void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st)
 {
     const int nb = (int)(n / 60000 + 1);  // includes the (possibly empty) final block
