@@ -477,3 +477,33 @@ def test_random_shapes_tolerances_and_field_kinds_vs_oracle(ctx, oracle):
         ctx.decode(buf, f.shape, enc)
         assert bits_equal(buf.download(np.float64, f.size), oracle.decode(want, f.shape)), tag
         buf.free()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 64, 80), (200, 120, 72)])
+def test_zero_minimum_and_nans_on_the_fused_minmax_path(ctx, oracle, shape):
+    """All four levels fused: min/max of the field and of the coefficients come out of the forward kernels.  The
+    reference's scan semantics must survive that: the sign of a zero minimum is the sign of the LAST zero in
+    memory order (it shows in midval / minval_vec), NaN samples are skipped by fmin/fmax."""
+    nx, ny, nz = shape
+    rs = np.random.RandomState(nx)
+    f = np.abs(synth.field(nx, ny, nz, seed=8)) + 0.25
+    flat = f.reshape(-1)
+    pos = np.sort(rs.choice(flat.size, 3, replace=False))
+    for zeros in ([0.0, -0.0, 0.0], [-0.0, 0.0, -0.0]):
+        flat[pos] = zeros
+        want = oracle.encode(f, 1e-6)
+        buf = ctx.to_device(f)
+        enc, _ = ctx.encode(buf, f.shape, 1e-6)
+        buf.free()
+        assert float(enc["midval"]).hex() == float(want["midval"]).hex()
+        assert bits_equal(enc["minval_vec"], want["minval_vec"]) and bits_equal(enc["deps_vec"], want["deps_vec"])
+        assert np.array_equal(enc["data"], want["data"])
+    # a field that is zero almost everywhere: the coefficient minimum of later planes is a zero as well
+    g = np.zeros_like(f)
+    g.reshape(-1)[pos] = [1.0, -0.0, 2.0]
+    want = oracle.encode(g, 1e-4)
+    buf = ctx.to_device(g)
+    enc, _ = ctx.encode(buf, g.shape, 1e-4)
+    buf.free()
+    assert enc["nlay"] == want["nlay"] and bits_equal(enc["minval_vec"], want["minval_vec"])
+    assert np.array_equal(enc["data"], want["data"])

@@ -150,6 +150,7 @@ struct wr_ctx {
     bool keep_residual = false;
     double* d_cutoff = nullptr; size_t cutoff_elems = 0;  // local cutoff vector (mx*my*mz > 1 only)
     double* d_partial = nullptr; double* d_result = nullptr;
+    double* d_mm = nullptr; size_t mm_records = 0;  // min/max records of the fused forward transform
     unsigned long long* d_idx = nullptr;
     // pinned host
     double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index
@@ -620,7 +621,7 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cutoff);
-    (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx);
+    (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx); (void)hipFree(c->d_mm);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_hist) (void)hipHostFree(c->h_hist);
     for (int l = 0; l < WR_NLAYMAX; l++) {
@@ -822,6 +823,50 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
     const size_t pitch = wr_plane_pitch(n);
     Prologue p;
     *resid = d_fld;
+    double lo, hi;
+    float ms = 0;
+    // When all four levels run on the fused kernels, those reduce min/max of the field and of the coefficient
+    // array on the way (no stand-alone passes, one host round trip instead of two).  The transform then runs
+    // before it is known whether the field is trivial; it is out of place, so nothing is lost if it is.
+    const size_t mm_records = (wtflag && use_fused(nx, ny, nz, kWavLvl) && !getenv("WR_NO_FUSED_MINMAX")) ? wrk::fused_minmax_records(nx, ny, nz) : 0;
+    if (mm_records) {
+        if (c->mm_records < mm_records) {
+            if (c->d_mm) HIPCHK(hipFree(c->d_mm));
+            c->d_mm = nullptr; c->mm_records = 0;
+            HIPCHK(hipMalloc(&c->d_mm, mm_records * 4 * sizeof(double)));
+            c->mm_records = mm_records;
+        }
+        memset(info, 0, sizeof(*info));
+        info->wlev = kWavLvl;
+        double* const d_in = d_fld;
+        HIPCHK(hipEventRecord(c->ev_b, c->stream));
+        wrk::transform_fwd_fused(d_in, slot->scratch, slot->lowbuf, nx, ny, nz, c->stream, c->d_mm, c->d_result);
+        HIPCHK(hipEventRecord(c->ev_c, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_result + 4, c->d_result, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->ev_mm, c->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventSynchronize(c->ev_mm));
+        p.lo = c->h_result[4]; p.hi = c->h_result[5];
+        lo = c->h_result[6]; hi = c->h_result[7];
+        if (p.lo == 0.0)  // sign of a zero minimum: the reference's scan semantics, rare path
+            if (int rc = read_minmax(c, d_in, n, false, &p.lo, &p.hi)) return rc;
+        if (p.lo != p.lo || p.hi != p.hi) return fail(WR_ERR_ARG, "field is all NaN");
+        info->halfspanval = (p.hi - p.lo) / 2;
+        info->midval = p.lo + info->halfspanval;
+        p.trivial = info->halfspanval <= 2 * DBL_MIN;
+        if (verbose()) printf("Wavelet decomposition...\n");
+        if (p.trivial) {  // wrappers.cpp:256-266
+            info->ntot_enc = 0; info->nlay = 0; info->tolabs = 0;
+            return WR_OK;
+        }
+        d_fld = slot->scratch;  // d_fld := coefficients
+        *resid = d_fld;
+        if (verbose()) printf("Range encoding...\n");
+        info->tolabs = abs_tolerance(tolrel, p);
+        if (lo == 0.0)
+            if (int rc = read_minmax(c, d_fld, n, false, &lo, &hi)) return rc;
+        if (tm) { HIPCHK(hipEventElapsedTime(&ms, c->ev_b, c->ev_c)); tm->transform_ms = ms; tm->minmax_ms = 0; }
+    } else {
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     if (int rc = prologue(c, d_fld, n, wtflag, info, &p)) return rc;
     if (verbose()) printf("Wavelet decomposition...\n");
@@ -836,15 +881,14 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
     if (verbose()) printf("Range encoding...\n");
     info->tolabs = abs_tolerance(tolrel, p);
 
-    double lo, hi;
     if (int rc = read_minmax(c, d_fld, n, false, &lo, &hi)) return rc;
     HIPCHK(hipEventRecord(c->ev_d, c->stream));
-    float ms = 0;
     HIPCHK(hipEventSynchronize(c->ev_d));
     if (tm) {
         HIPCHK(hipEventElapsedTime(&ms, c->ev_b, c->ev_c)); tm->transform_ms = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); tm->minmax_ms = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev_c, c->ev_d)); tm->minmax_ms += ms;
+    }
     }
     unsigned ilay = 0;
     float quant_ms = 0;

@@ -113,11 +113,16 @@ __device__ inline void lift_fwd_two(const double s[6], const double d[5], double
 
 }  // namespace
 
+// MM_IN / MM_OUT: also reduce min/max of the samples read (the whole level input: level 0 = the field) / of the
+// coefficients stored to their final positions (mm_lll: including the low-pass octant, i.e. this is the last
+// level), one {in lo, in hi, out lo, out hi} record per wave in mm_partial -- replaces the two stand-alone
+// min/max passes of the encoder (wrappers.cpp:244-250, 308-314) at ~3 % more vector instructions.
+template <bool MM_IN, bool MM_OUT>
 __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const double* __restrict__ src, size_t s_sy, size_t s_sz,  // level input (x stride 1)
     double* __restrict__ dst, size_t d_sy, size_t d_sz,        // coefficient array (final positions)
     double* __restrict__ low, size_t l_sy, size_t l_sz,        // low-pass octant destination
-    int n1, int n2, int n3, int zps
+    int n1, int n2, int n3, int zps, double* __restrict__ mm_partial, int mm_lll
 #ifdef WR_STAMP
     , unsigned long long* __restrict__ stamp_out  // diagnostic build: per-workgroup phase cycle sums
 #endif
@@ -142,6 +147,9 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const int z0 = blockIdx.y * zps;
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
+
+    const double mm_nan = __builtin_nan("");
+    double in_lo = mm_nan, in_hi = mm_nan, out_lo = mm_nan, out_hi = mm_nan;  // fmin/fmax skip NaNs, as the reference's scan does
 
     // per-thread source offsets of its staged 16-byte chunks (same for every plane).  Rows are
     // mirrored at the y edges by choosing the source row; a chunk that would need x mirroring
@@ -199,6 +207,10 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
         auto two_rows = [&](int row) {
             const double2* r = rp + row * RX + jp;
             const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5];
+            if (MM_IN) {  // v2, v3 are this lane's own two pairs: all lanes and rows together cover every sample read
+                in_lo = fmin(fmin(in_lo, v2.x), fmin(v2.y, fmin(v3.x, v3.y)));
+                in_hi = fmax(fmax(in_hi, v2.x), fmax(v2.y, fmax(v3.x, v3.y)));
+            }
             const double s[6] = {v0.x, v1.x, v2.x, v3.x, v4.x, v5.x};
             const double d[5] = {v0.y, v1.y, v2.y, v3.y, v4.y};
             double lo0, hi0, lo1, hi1;
@@ -296,15 +308,30 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                 // addresses, DPP + selects) -- profiles/r01/NOTES.md.
                 if (own_x && oy + yp < m2 && j >= z0 && j < z1) {
                     double* base = dst + ((q & 1) ? oct_x : 0) + ((q & 2) ? oct_y : 0) + (size_t)yp * d_sy;
-                    if ((q & 3) == 0) (low + (size_t)j * l_sz + (size_t)yp * l_sy)[lpos] = S2 * WR_ZETA;
-                    else (base + (size_t)j * d_sz)[pos0] = S2 * WR_ZETA;
-                    (base + (size_t)(m3 + j) * d_sz)[pos0] = D2 * WR_IZETA;
+                    const double clo = S2 * WR_ZETA, chi = D2 * WR_IZETA;
+                    if ((q & 3) == 0) (low + (size_t)j * l_sz + (size_t)yp * l_sy)[lpos] = clo;
+                    else (base + (size_t)j * d_sz)[pos0] = clo;
+                    (base + (size_t)(m3 + j) * d_sz)[pos0] = chi;
+                    if (MM_OUT) {
+                        out_lo = fmin(out_lo, chi); out_hi = fmax(out_hi, chi);
+                        if ((q & 3) != 0 || mm_lll) { out_lo = fmin(out_lo, clo); out_hi = fmax(out_hi, clo); }
+                    }
                 }
                 p2[q] = D2;
             }
             p1[q] = D1; q1[q] = S1; sr1[q] = a[q]; dr1[q] = b[q];
         }
         STAMP(5);
+    }
+    if (MM_IN || MM_OUT) {
+        for (int o = 32; o > 0; o >>= 1) {
+            if (MM_IN) { in_lo = fmin(in_lo, __shfl_down(in_lo, o, 64)); in_hi = fmax(in_hi, __shfl_down(in_hi, o, 64)); }
+            out_lo = fmin(out_lo, __shfl_down(out_lo, o, 64)); out_hi = fmax(out_hi, __shfl_down(out_hi, o, 64));
+        }
+        if (lane == 0) {
+            double* rec = mm_partial + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVE + w) * 4;
+            rec[0] = in_lo; rec[1] = in_hi; rec[2] = out_lo; rec[3] = out_hi;
+        }
     }
 #ifdef WR_STAMP
     if (stamp_out && lane == 0)
@@ -613,15 +640,75 @@ extern "C" unsigned long long* wr_stamp_buffer(size_t nwaves)
 }
 #endif
 
-void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
+// grid of one fused forward level
+static dim3 fwd_grid(int n1, int n2, int n3, int* zps_out)
+{
+    const int m1 = n1 / 2, m2 = n2 / 2, m3 = n3 / 2;
+    const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
+    const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_BYTES));
+    *zps_out = zps;
+    return dim3(tiles, (m3 + zps - 1) / zps);
+}
+
+// min/max records (4 doubles each) transform_fwd_fused writes when it reduces min/max on the way; 0 if the
+// shape does not run all four levels fused (the stand-alone reductions are used then)
+size_t fused_minmax_records(int nx, int ny, int nz)
+{
+    if (fused_levels(nx, ny, nz, false) != 4) return 0;
+    size_t tot = 0;
+    for (int l = 0; l < 4; l++) {
+        int zps;
+        const dim3 g = fwd_grid(nx >> l, ny >> l, nz >> l, &zps);
+        tot += (size_t)g.x * g.y * NWAVE;
+    }
+    return tot;
+}
+
+// 4-wide records -> result[0..3] = {in lo, in hi, out lo, out hi}.  The input range comes from the first
+// `n_in` records only (level 0 reads the field; deeper levels read low-pass boxes).
+__global__ __launch_bounds__(256) void k_minmax_final4(const double* __restrict__ rec, int n_in, int n_all, double* __restrict__ result)
+{
+    const double nan = __builtin_nan("");
+    double v[4] = {nan, nan, nan, nan};
+    for (int i = threadIdx.x; i < n_all; i += blockDim.x) {
+        if (i < n_in) { v[0] = fmin(v[0], rec[4 * i]); v[1] = fmax(v[1], rec[4 * i + 1]); }
+        v[2] = fmin(v[2], rec[4 * i + 2]); v[3] = fmax(v[3], rec[4 * i + 3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        v[0] = fmin(v[0], __shfl_down(v[0], o, 64)); v[1] = fmax(v[1], __shfl_down(v[1], o, 64));
+        v[2] = fmin(v[2], __shfl_down(v[2], o, 64)); v[3] = fmax(v[3], __shfl_down(v[3], o, 64));
+    }
+    __shared__ double sh[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; k++) sh[w][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) {
+            v[0] = fmin(v[0], sh[i][0]); v[1] = fmax(v[1], sh[i][1]); v[2] = fmin(v[2], sh[i][2]); v[3] = fmax(v[3], sh[i][3]);
+        }
+        for (int k = 0; k < 4; k++) result[k] = v[k];
+    }
+}
+
+// mm_partial != nullptr (needs fused_minmax_records() > 0): min/max of the field and of the coefficient array
+// are reduced on the way and land in mm_result[0..3].
+void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st,
+                         double* mm_partial, double* mm_result)
 {
     static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES); });
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)k_fwd_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_fwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_fwd_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    });
     const size_t d_sy = (size_t)nx, d_sz = (size_t)nx * ny;
     const int nfused = fused_levels(nx, ny, nz, false);
+    const bool mm = mm_partial != nullptr && nfused == 4;
     const double* in = src;
     size_t in_sy = d_sy, in_sz = d_sz;
     double* lb = lowbuf;
+    double* rec = mm_partial;
+    int n_in = 0, n_all = 0;
     for (int l = 0; l < nfused; l++) {
         const int n1 = nx >> l, n2 = ny >> l, n3 = nz >> l;
         const int m1 = n1 / 2, m2 = n2 / 2, m3 = n3 / 2;
@@ -630,19 +717,31 @@ void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int n
         // the last fused level leaves its low-pass octant in the coefficient array itself
         if (l < nfused - 1) { lo = lb; lo_sy = (size_t)m1; lo_sz = (size_t)m1 * m2; }
         else { lo = dst; lo_sy = d_sy; lo_sz = d_sz; }
-        const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + TYP - 1) / TYP);
-        const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_BYTES));
-        dim3 grid(tiles, (m3 + zps - 1) / zps);
+        int zps;
+        const dim3 grid = fwd_grid(n1, n2, n3, &zps);
+        const int lll = l == nfused - 1;
 #ifdef WR_STAMP
-        hipLaunchKernelGGL(k_fwd_fused, grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
-                           lo_sz, n1, n2, n3, zps, l == 0 ? g_stamp_buf : nullptr);
+        hipLaunchKernelGGL((k_fwd_fused<false, false>), grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
+                           lo_sz, n1, n2, n3, zps, (double*)nullptr, 0, l == 0 ? g_stamp_buf : nullptr);
 #else
-        hipLaunchKernelGGL(k_fwd_fused, grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
-                           lo_sz, n1, n2, n3, zps);
+        if (!mm)
+            hipLaunchKernelGGL((k_fwd_fused<false, false>), grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
+                               lo_sz, n1, n2, n3, zps, (double*)nullptr, 0);
+        else if (l == 0)
+            hipLaunchKernelGGL((k_fwd_fused<true, true>), grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
+                               lo_sz, n1, n2, n3, zps, rec, lll);
+        else
+            hipLaunchKernelGGL((k_fwd_fused<false, true>), grid, dim3(NTHR), LDS_BYTES, st, in, in_sy, in_sz, dst, d_sy, d_sz, lo, lo_sy,
+                               lo_sz, n1, n2, n3, zps, rec, lll);
 #endif
+        const int nrec = (int)(grid.x * grid.y * NWAVE);
+        if (l == 0) n_in = nrec;
+        n_all += nrec;
+        rec += (size_t)nrec * 4;
         in = lo; in_sy = lo_sy; in_sz = lo_sz;
         lb += (size_t)m1 * m2 * m3;
     }
+    if (mm) hipLaunchKernelGGL(k_minmax_final4, dim3(1), dim3(256), 0, st, mm_partial, n_in, n_all, mm_result);
     // coarser levels whose boxes are odd somewhere: general kernels, in place on the corner box of
     // dst; the input array has been fully consumed by level 0 and serves as their ping-pong scratch
     for (int k = nfused; k < 4; k++) transform_level(dst, src, nx, ny, nz, k, false, st);
