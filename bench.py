@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
     ap.add_argument("--resident", action="store_true", help="fields start and end in HBM (round-1 measurement) instead of host buffers")
     ap.add_argument("--slots", type=int, default=0, help="device work-space slots (0: library default)")
+    ap.add_argument("--pool", type=int, default=-1, help="coder-pool worker threads shared by all fields in flight (-1: one per CPU of this rank; 0: no pool, "
+                    "every call runs its own --threads coder threads)")
+    ap.add_argument("--dec-streams", type=int, default=6, help="plane streams a pool worker's decoder loop interleaves (1..6)")
     args = ap.parse_args()
     tols = [float(t) for t in args.tols.split(",")]
     n = args.size
@@ -259,6 +262,9 @@ def main():
     share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
     jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode)
     limits["cpu_affinity_share"] = share
+    pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
+    if pool_workers:
+        api.set_coder_pool(pool_workers, args.dec_streams)
 
     # One lane per field of the batch (jobs x tolerance settings: independent jobs that run concurrently on
     # the one GPU; they all code this rank's synthetic field).  A lane is a two-stage pipeline -- encoder
@@ -412,7 +418,9 @@ def main():
                                       ("BASELINE configs[3]: independent 512^3 fields sharded one per GPU" if world > 1 else "BASELINE configs[1]") if n == 512
                                       else "parity-size run"),
                        "boundary": "host buffers (pinned), wr_encode_host / wr_decode_host" if host_mode else "device buffers, wr_encode_device / wr_decode_device",
-                       "field_shards": world, "range_coder_threads": {"encode": args.enc_threads or args.threads, "decode": args.threads},
+                       "field_shards": world,
+                       "range_coder": ({"pool_workers": pool_workers, "decoder_streams_per_loop": args.dec_streams, "encoder_streams_per_loop": 3} if pool_workers
+                                       else {"threads_per_call": {"encode": args.enc_threads or args.threads, "decode": args.threads}}),
                        "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": len(lanes), "sizing": limits, "pipeline": "encode(k+1) overlaps decode(k)",
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -453,6 +461,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # one field alone on the idle machine, a coder thread per plane: the latency a single
             # encoding_wrap / decoding_wrap caller sees (outside the timed region)
+            api.set_coder_pool(0)
             api.set_threads(8)
             ln = lanes[-1]
             if host_mode:

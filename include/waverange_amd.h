@@ -149,6 +149,13 @@ void wr_set_threads(int nthreads);
 /* a different count for the encoder alone (0 = follow wr_set_threads, which also resets this): the
  * encoder interleaves 2 planes as efficiently as 3-4, the decoder is at its best with 4 per thread */
 void wr_set_encoder_threads(int nthreads);
+/* Process-wide coder pool for callers that keep several fields in flight: nthreads > 0 starts that many worker
+ * threads which code the plane streams of ALL concurrent encode / decode calls (wr_set_threads is then
+ * ignored); 0 stops it (default: every call runs its own coder threads).  A worker interleaves up to 3 encoder
+ * or decoder_streams (1..6, default 6; < 1 keeps the setting) decoder streams in one symbol loop, whichever
+ * fields they belong to, so a decoder loop is not limited to the 3-4 planes of one field, and the number of
+ * running coder threads never exceeds nthreads.  Same bytes either way. */
+void wr_set_coder_pool(int nthreads, int decoder_streams);
 /* whether the drop-in encoding_wrap leaves the residual in fld_1d as the reference does (default 1,
  * WR_WRITEBACK_RESIDUAL in the environment): callers that discard the array save a field download */
 void wr_set_writeback_residual(int on);
@@ -254,6 +261,13 @@ void wr_range_encode_multi(int count, const unsigned char *const *sym, size_t n,
                            unsigned char *const *out, size_t *lens);
 void wr_range_decode_multi(int count, const unsigned char *const *in, const size_t *len,
                            unsigned char *const *sym, size_t n, size_t *produced);
+
+/* the same through the coder pool (wr_set_coder_pool must have started it): `count` planes of their own lengths
+ * n[k], coded by the pool's workers next to whatever else is queued; returns when all of them are done */
+int wr_range_encode_pool(int count, const unsigned char *const *sym, const size_t *n,
+                         unsigned char *const *out, size_t *lens);
+int wr_range_decode_pool(int count, const unsigned char *const *in, const size_t *len,
+                         unsigned char *const *sym, const size_t *n, size_t *produced);
 
 /* --- measurement hook for bench.py: runs `reps` forward (lvl>0) or inverse transforms of an
  * nx*ny*nz field back to back on the context's stream and returns the average duration of

@@ -192,3 +192,56 @@ def test_rngcod13_primitives_and_index_map(api, oracle, golden):
         o = [C.c_int() for _ in range(4)]
         L.ind_p2w_3d(4, n1, n2, n3, i1, i2, i3, *[C.byref(v) for v in o])
         assert tuple(v.value for v in o) == (l, w1, w2, w3)
+
+
+def test_coder_pool_same_bytes_as_oracle(oracle):
+    """The process-wide coder pool (wr_set_coder_pool): planes of many lengths and kinds, submitted from several
+    threads at once, coded by 1, 2 and 3 workers with 2, 4 and 6 decoder streams per loop -- streams join and
+    leave the interleaved loops at block boundaries.  Every stream must equal the oracle's bytes, every plane
+    must come back."""
+    import threading
+    from waverange_amd import api
+    rs = np.random.RandomState(5)
+    planes = []
+    for n in (1, 59999, 60000, 60001, 120000, 150000, 333333, 600000, 777777, 1200000):
+        planes.append(rs.randint(0, 256, n).astype(np.uint8))                                     # noise
+        planes.append(rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.8, 0.2]))            # two symbols
+        planes.append(np.where(rs.random_sample(n) < 0.999, 7, rs.randint(0, 16, n)).astype(np.uint8))  # one dominant
+        planes.append(rs.choice(np.array([3, 4, 5, 250], np.uint8), size=n))                      # four symbols
+    want = [oracle.range_encode(p) for p in planes]
+    try:
+        for workers, streams in ((1, 2), (2, 4), (3, 6)):
+            api.set_coder_pool(workers, streams)
+            errors = []
+
+            def client(sel):
+                try:
+                    mine = [planes[i] for i in sel]
+                    enc = api.range_encode_pool(mine)
+                    for i, e in zip(sel, enc):
+                        assert np.array_equal(e, want[i]), ("encode", i, planes[i].size)
+                    dec, got = api.range_decode_pool(enc, [p.size for p in mine])
+                    for i, d, g in zip(sel, dec, got):
+                        assert g == planes[i].size and np.array_equal(d, planes[i]), ("decode", i)
+                except Exception as exc:  # noqa: BLE001
+                    errors.append(exc)
+
+            idx = list(range(len(planes)))
+            rs.shuffle(idx)
+            ths = [threading.Thread(target=client, args=(idx[k::4],)) for k in range(4)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            assert not errors, errors[:2]
+        # damaged and truncated streams next to good ones: reported per plane, the others unharmed
+        api.set_coder_pool(2, 6)
+        good = [planes[30], planes[25], planes[20]]
+        enc = api.range_encode_pool(good)
+        bad = enc[1].copy()
+        bad[len(bad) // 2: len(bad) // 2 + 40] ^= 0xA5
+        dec, got = api.range_decode_pool([enc[0], bad, enc[2][: len(enc[2]) // 2]], [p.size for p in good])
+        assert got[0] == good[0].size and np.array_equal(dec[0], good[0])
+        assert got[2] != good[2].size
+    finally:
+        api.set_coder_pool(0)

@@ -112,6 +112,7 @@ def lib():
     L.wr_host_free.argtypes = [_vp]
     L.wr_set_device_slots.argtypes = [C.c_int, C.c_int]
     L.wr_set_writeback_residual.argtypes = [C.c_int]
+    L.wr_set_coder_pool.argtypes = [C.c_int, C.c_int]
     L.wr_stat.restype = C.c_ulong
     L.wr_stat.argtypes = [C.c_int]
     L.wr_range_encode_bound.restype = C.c_size_t
@@ -124,6 +125,8 @@ def lib():
     L.wr_range_encode_multi.argtypes = [C.c_int, _vp, C.c_size_t, _vp, _vp]
     L.wr_range_decode_multi.restype = None
     L.wr_range_decode_multi.argtypes = [C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]
+    L.wr_range_encode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
+    L.wr_range_decode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_bench_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     # drop-in symbols (reference src/core/wrappers.h:53,70,75)
     L.setup_wr.argtypes = [C.c_int] * 3 + [_u8p, _ulp]
@@ -152,6 +155,12 @@ def set_threads(n, encoder=0):
     """coder threads per call; `encoder` > 0 gives the encoder its own count"""
     lib().wr_set_threads(int(n))
     lib().wr_set_encoder_threads(int(encoder))
+
+
+def set_coder_pool(nthreads, decoder_streams=0):
+    """process-wide coder pool (wr_set_coder_pool): nthreads workers code the planes of all concurrent calls;
+    0 stops it"""
+    lib().wr_set_coder_pool(int(nthreads), int(decoder_streams))
 
 
 def set_device_slots(device, nslots):
@@ -229,6 +238,27 @@ def range_decode_multi(streams, n):
     lib().wr_range_decode_multi(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
                                 (C.c_void_p * k)(*[o.ctypes.data for o in outs]), n, got)
     return [o[:n] for o in outs], [got[i] for i in range(k)]
+
+
+def range_encode_pool(planes):
+    """Planes of any lengths through the coder pool (set_coder_pool first)."""
+    ps = [np.ascontiguousarray(p, dtype=np.uint8).ravel() for p in planes]
+    k = len(ps)
+    outs = [np.empty(lib().wr_range_encode_bound(p.size), dtype=np.uint8) for p in ps]
+    lens = (C.c_size_t * k)()
+    _check(lib().wr_range_encode_pool(k, (C.c_void_p * k)(*[p.ctypes.data for p in ps]), (C.c_size_t * k)(*[p.size for p in ps]),
+                                      (C.c_void_p * k)(*[o.ctypes.data for o in outs]), lens))
+    return [o[:lens[i]].copy() for i, o in enumerate(outs)]
+
+
+def range_decode_pool(streams, ns):
+    ss = [np.ascontiguousarray(s, dtype=np.uint8).ravel() for s in streams]
+    k = len(ss)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for n in ns]
+    got = (C.c_size_t * k)()
+    _check(lib().wr_range_decode_pool(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
+                                      (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*ns), got))
+    return [o[:n] for o, n in zip(outs, ns)], [got[i] for i in range(k)]
 
 
 # ---------------------------------------------------------------------------------------

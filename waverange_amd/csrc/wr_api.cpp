@@ -542,6 +542,10 @@ void wr_set_threads(int nthreads) { g_threads.store(nthreads < 1 ? 1 : nthreads)
 void wr_set_encoder_threads(int nthreads) { g_enc_threads.store(nthreads < 0 ? 0 : nthreads); }
 void wr_set_writeback_residual(int on) { g_writeback.store(on ? 1 : 0); }
 unsigned long wr_stat(int what) { return (what >= 0 && what < 4) ? g_stat[what].load() : 0; }
+void wr_set_coder_pool(int nthreads, int decoder_streams)
+{
+    wrrc::pool_configure(nthreads < 0 ? 0 : nthreads, decoder_streams);
+}
 
 int wr_set_device_slots(int device, int nslots)
 {
@@ -1037,7 +1041,11 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
     // on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
     // their number is known and each thread codes its group with the symbol loops interleaved.
-    const bool per_plane = encoder_threads() >= WR_NLAYMAX;
+    const bool pooled = wrrc::pool_threads() > 0;  // the process-wide coder pool codes the planes (wr_set_coder_pool)
+    const bool per_plane = !pooled && encoder_threads() >= WR_NLAYMAX;
+    wrrc::PlaneJob jobs[WR_NLAYMAX];
+    wrrc::JobBatch batch;
+    unsigned jobs_submitted = 0;
     auto code_group = [&](unsigned l0, unsigned l1) {
         (void)hipSetDevice(dev);
         for (unsigned l = l0; l < l1; l++)
@@ -1122,17 +1130,40 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             if ((rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) == WR_OK) rc = xfer_wait(&c->x_field);
         }
         // The slot's plane buffers must not be reused before their downloads are done (the coder threads wait
-        // for the same transfers; xfer_wait is safe to call from both sides).
-        for (unsigned l = 0; l < planes_started; l++)
+        // for the same transfers; xfer_wait is safe to call from both sides).  With the coder pool, every plane
+        // is handed over the moment it is on the host.
+        for (unsigned l = 0; l < planes_started; l++) {
             if (xfer_wait(&c->x_plane[l]) != WR_OK) copy_failed[l] = 1;
+            if (pooled && rc == WR_OK && !copy_failed[l]) {
+                wrrc::PlaneJob& j = jobs[l];
+                j.kind = wrrc::PlaneJob::kEncode;
+                j.src = c->h_plane[l]; j.dst = c->enc_buf[l]; j.n = n; j.hist = c->h_hist + l * hist_per_plane;
+                wrrc::pool_submit(&j, 1, &batch);
+                jobs_submitted = l + 1;
+            }
+        }
         for (unsigned l = 0; l < planes_started; l++) local.d2h_ms += (float)c->x_plane[l].ms;
         t_gpu_done = now();
         // the slot goes back here: its planes are on the host
     } catch (const std::exception& e) {
         workers.join();
+        wrrc::pool_wait(&batch);
         return fail(WR_ERR_ARG, std::string("encode: ") + e.what());
     }
-    if (rc == WR_OK && !per_plane && info->nlay) {
+    if (pooled) {
+        wrrc::pool_wait(&batch);
+        for (unsigned l = 0; l < jobs_submitted; l++) { lens[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
+        if (rc == WR_OK && verbose())  // wrappers.cpp:401-409, 430
+            for (unsigned l = 0; l < info->nlay; l++) {
+                const uint8_t* q = c->h_plane[l];
+                unsigned lo = q[0], hi = q[0];
+                for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+                char b[256];
+                snprintf(b, sizeof b, "imin=%u imax=%u med=%g\nlen_out_q=%lu ntot=%lu\n", lo, hi,
+                         q[n / 2] * info->deps_vec[l] + info->minval_vec[l], (unsigned long)lens[l], (unsigned long)n);
+                logs[l] = b;
+            }
+    } else if (rc == WR_OK && !per_plane && info->nlay) {
         try {
             const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)encoder_threads());
             for (unsigned g = 0; g < groups; g++)
@@ -1216,12 +1247,25 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     int up_err[WR_NLAYMAX] = {0};
     Sem sem(coder_threads());
     const int dev = c->device;
-    // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved
-    const int groups = std::min(nlay, coder_threads());
+    // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved, or the process-wide
+    // coder pool (wr_set_coder_pool), whose workers interleave planes of several fields
+    const bool pooled = wrrc::pool_threads() > 0;
+    const int groups = pooled ? 0 : std::min(nlay, coder_threads());
     int rc = WR_OK;
     double t_phase = 0, t_coded = 0;
     try {
         SlotLease slot;
+        if (pooled) {
+            wrrc::PlaneJob jobs[WR_NLAYMAX];
+            wrrc::JobBatch batch;
+            for (int l = 0; l < nlay; l++) {
+                jobs[l].kind = wrrc::PlaneJob::kDecode;
+                jobs[l].src = data_enc + off[l]; jobs[l].src_len = info->len_enc_vec[l]; jobs[l].dst = c->h_plane[l]; jobs[l].n = n;
+            }
+            wrrc::pool_submit(jobs, nlay, &batch);
+            wrrc::pool_wait(&batch);
+            for (int l = 0; l < nlay; l++) { got[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
+        }
         // With a thread per plane the planes finish at different times (a leading plane of a smooth field
         // decodes 2-3 times faster than a noise plane): if a slot is free right now (and not the last one),
         // take it and let every thread upload its plane the moment it is decoded, while the later planes
@@ -1408,6 +1452,35 @@ void wr_range_encode_multi(int count, const unsigned char* const* sym, size_t n,
 void wr_range_decode_multi(int count, const unsigned char* const* in, const size_t* len, unsigned char* const* sym, size_t n, size_t* produced)
 {
     wrrc::decode_planes(count, in, len, sym, n, produced);
+}
+
+int wr_range_encode_pool(int count, const unsigned char* const* sym, const size_t* n, unsigned char* const* out, size_t* lens)
+{
+    if (wrrc::pool_threads() < 1) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
+    if (count < 1) return WR_OK;
+    std::vector<wrrc::PlaneJob> jobs((size_t)count);
+    wrrc::JobBatch batch;
+    for (int k = 0; k < count; k++) { jobs[k].kind = wrrc::PlaneJob::kEncode; jobs[k].src = sym[k]; jobs[k].n = n[k]; jobs[k].dst = out[k]; }
+    wrrc::pool_submit(jobs.data(), count, &batch);
+    wrrc::pool_wait(&batch);
+    for (int k = 0; k < count; k++) lens[k] = jobs[k].result;
+    return WR_OK;
+}
+
+int wr_range_decode_pool(int count, const unsigned char* const* in, const size_t* len, unsigned char* const* sym, const size_t* n,
+                         size_t* produced)
+{
+    if (wrrc::pool_threads() < 1) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
+    if (count < 1) return WR_OK;
+    std::vector<wrrc::PlaneJob> jobs((size_t)count);
+    wrrc::JobBatch batch;
+    for (int k = 0; k < count; k++) {
+        jobs[k].kind = wrrc::PlaneJob::kDecode; jobs[k].src = in[k]; jobs[k].src_len = len[k]; jobs[k].dst = sym[k]; jobs[k].n = n[k];
+    }
+    wrrc::pool_submit(jobs.data(), count, &batch);
+    wrrc::pool_wait(&batch);
+    for (int k = 0; k < count; k++) produced[k] = jobs[k].result;
+    return WR_OK;
 }
 
 int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl, int reps, double* ms_out)

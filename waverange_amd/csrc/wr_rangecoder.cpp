@@ -12,7 +12,11 @@
 
 #include <string.h>
 
+#include <chrono>
+#include <deque>
+#include <memory>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -241,49 +245,92 @@ inline void encode_block_header(Enc& e, const uint8_t* s, uint32_t bs, const uin
 // than the interleaving gains (EPYC 9575F: 1 plane 380-500 Msym/s, 2: 700, 3: 680, 4: 560 in total).
 constexpr int kMaxEncStreams = 3;
 
+namespace {
+
+// A set of up to kMaxEncStreams plane streams that advance block by block in lockstep on one thread
+// (block loop of wrappers.cpp:85-128: a full final block is followed by an empty one).  Streams may join at
+// any block boundary and leave when they end; slots stay compact so that the interleaved loop always runs on
+// slots 0 .. count-1.
+class EncGroup {
+public:
+    struct Stream {
+        const uint8_t* sym; size_t n, done, blk; const uint16_t* hist;
+        void* tag;
+    };
+    int count() const { return count_; }
+    bool full() const { return count_ == kMaxEncStreams; }
+    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag)
+    {
+        const int k = count_++;
+        es_[k] = new (store_[k]) Enc(out);
+        st_[k] = Stream{sym, n, 0, 0, hist, tag};
+    }
+    // one block of every stream; on_end(tag, stream length) for the streams that ended with it
+    template <class OnEnd>
+    void step(OnEnd on_end)
+    {
+        uint32_t bs[kMaxEncStreams];
+        bool all_full = true, topsel = false;  // topsel: some plane's largest symbol holds > 2 % of this block
+        for (int k = 0; k < count_; k++) {
+            Stream& s = st_[k];
+            const size_t left = s.n - s.done;
+            bs[k] = left < kBlock ? (uint32_t)left : kBlock;
+            ss_[k] = s.sym + s.done;
+            encode_block_header(*es_[k], ss_[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
+            all_full = all_full && bs[k] == kBlock;
+            topsel = topsel || (uint64_t)tabs_[k][tops_[k]].sy * 50 > bs[k];
+        }
+        if (all_full) {
+            switch (count_) {
+            case 1: topsel ? encode_symbols<kBlock, true>(*es_[0], ss_[0], kBlock, tabs_[0], tops_[0]) : encode_symbols<kBlock, false>(*es_[0], ss_[0], kBlock, tabs_[0], tops_[0]); break;
+            case 2: topsel ? encode_symbols_multi<2, true>(es_, ss_, tabs_, tops_) : encode_symbols_multi<2, false>(es_, ss_, tabs_, tops_); break;
+            default: topsel ? encode_symbols_multi<3, true>(es_, ss_, tabs_, tops_) : encode_symbols_multi<3, false>(es_, ss_, tabs_, tops_); break;
+            }
+        } else {
+            for (int k = 0; k < count_; k++) {
+                if (bs[k] == kBlock) encode_symbols<kBlock, true>(*es_[k], ss_[k], kBlock, tabs_[k], tops_[k]);
+                else if (bs[k]) encode_symbols<0, true>(*es_[k], ss_[k], bs[k], tabs_[k], tops_[k]);
+            }
+        }
+        for (int k = 0; k < count_;) {
+            st_[k].done += bs[k];
+            st_[k].blk++;
+            if (bs[k] == kBlock) { k++; continue; }
+            es_[k]->freq(1, 0, 2);  // "no more blocks"
+            on_end(st_[k].tag, es_[k]->finish());
+            // the last slot moves into the hole (its block size with it: it has not been looked at yet)
+            const int last = --count_;
+            if (k != last) {
+                es_[k] = new (store_[k]) Enc(*es_[last]);
+                st_[k] = st_[last];
+                bs[k] = bs[last];
+            }
+        }
+    }
+
+private:
+    int count_ = 0;
+    Enc* es_[kMaxEncStreams];
+    alignas(Enc) unsigned char store_[kMaxEncStreams][sizeof(Enc)];
+    Stream st_[kMaxEncStreams];
+    SymEntry tabs_[kMaxEncStreams][256];
+    uint32_t tops_[kMaxEncStreams];
+    const uint8_t* ss_[kMaxEncStreams];
+};
+
+}  // namespace
+
 void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens)
 {
-    // block loop of wrappers.cpp:85-128: a full final block is followed by an empty one.  All
-    // planes of a field have the same length, hence the same block boundaries: they advance in
-    // lockstep, block by block.
-    if (count < 1) return;
-    if (count > kMaxEncStreams) {  // more planes than one loop interleaves well: two halves, one after the other
-        const int h = (count + 1) / 2;
-        encode_planes(h, sym, n, out, hists, lens);
-        encode_planes(count - h, sym + h, n, out + h, hists ? hists + h : nullptr, lens + h);
-        return;
-    }
-    Enc* es[kMaxStreams];
-    alignas(Enc) unsigned char store[kMaxStreams][sizeof(Enc)];
-    for (int k = 0; k < count; k++) es[k] = new (store[k]) Enc(out[k]);
-    SymEntry tabs[kMaxStreams][256];
-    uint32_t tops[kMaxStreams];
-    const uint8_t* ss[kMaxStreams];
-    size_t done = 0, blk = 0;
-    for (;; blk++) {
-        const size_t left = n - done;
-        const uint32_t bs = left < kBlock ? (uint32_t)left : kBlock;
-        for (int k = 0; k < count; k++) {
-            ss[k] = sym[k] + done;
-            encode_block_header(*es[k], ss[k], bs, (hists && hists[k]) ? hists[k] + blk * 256 : nullptr, tabs[k], &tops[k]);
+    // up to kMaxEncStreams planes at a time in one symbol loop; further planes join as earlier ones end
+    EncGroup g;
+    int next = 0;
+    while (next < count || g.count()) {
+        while (next < count && !g.full()) {
+            g.add(sym[next], n, out[next], (hists && hists[next]) ? hists[next] : nullptr, lens + next);
+            next++;
         }
-        bool topsel = false;  // some plane's largest symbol holds > 2 % of this block
-        for (int k = 0; k < count; k++) topsel = topsel || (uint64_t)tabs[k][tops[k]].sy * 50 > bs;
-        if (bs == kBlock) {
-            switch (count) {
-            case 1: topsel ? encode_symbols<kBlock, true>(*es[0], ss[0], bs, tabs[0], tops[0]) : encode_symbols<kBlock, false>(*es[0], ss[0], bs, tabs[0], tops[0]); break;
-            case 2: topsel ? encode_symbols_multi<2, true>(es, ss, tabs, tops) : encode_symbols_multi<2, false>(es, ss, tabs, tops); break;
-            default: topsel ? encode_symbols_multi<3, true>(es, ss, tabs, tops) : encode_symbols_multi<3, false>(es, ss, tabs, tops); break;
-            }
-        } else if (bs) {
-            for (int k = 0; k < count; k++) encode_symbols<0, true>(*es[k], ss[k], bs, tabs[k], tops[k]);
-        }
-        done += bs;
-        if (bs < kBlock) break;
-    }
-    for (int k = 0; k < count; k++) {
-        es[k]->freq(1, 0, 2);  // "no more blocks"
-        lens[k] = es[k]->finish();
+        g.step([](void* tag, size_t len) { *static_cast<size_t*>(tag) = len; });
     }
 }
 
@@ -542,6 +589,74 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
     for (int k = 0; k < NS; k++) { ds[k]->low = low[k]; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
 }
 
+// The same loop for more than four streams, with "this block has dominant symbols" tested at run time (the
+// branch has one outcome per stream for the whole block) instead of one instantiation per combination.
+template <int NS>
+void decode_symbols_multi_rt(Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
+{
+    uint32_t low[NS], range[NS];
+    const uint8_t* p[NS];
+    for (int k = 0; k < NS; k++) { low[k] = ds[k]->low; range[k] = ds[k]->range; p[k] = ds[k]->in + ds[k]->pos; }
+    for (uint32_t i = 0; i < kBlock; i++) {
+#pragma GCC unroll 8
+        for (int k = 0; k < NS; k++) {
+            const BlockModel* const m = ms[k];
+            uint32_t lw = low[k], rg = range[k];
+            const uint8_t* q = p[k];
+            {
+                const uint32_t sh = rg <= kBottom;
+                const uint32_t bits = ((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff;
+                lw = (lw << (8 * sh)) | (bits & (0u - sh));
+                rg <<= 8 * sh;
+                q += sh;
+            }
+            while (__builtin_expect(rg <= kBottom, 0)) {
+                lw = (lw << 8) | (((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff);
+                rg <<= 8;
+                q++;
+            }
+            const uint32_t help = rg / kBlock;
+            uint32_t c;
+            bool hit = false;
+            if (m->few) {
+                const uint32_t t1 = help * m->few_lt[1], t2 = help * m->few_lt[2], t3 = help * m->few_lt[3];
+                const uint32_t idx = (uint32_t)(lw >= t1) + (uint32_t)(lw >= t2) + (uint32_t)(lw >= t3);
+                const uint32_t t = select_u32(idx, select_u32(idx ^ 1, select_u32(idx ^ 2, t3, t2), t1), 0);
+                hit = true;
+                c = m->few_sym[idx];
+                lw -= t;
+                rg = select_u32(idx ^ (m->few - 1), help * m->few_sy[idx], rg - t);
+            } else if (m->mps_on) {
+                const uint32_t a0 = help * m->mps_lt[0], a1 = help * m->mps_lt[1];
+                const uint32_t w0 = m->mps_is_top[0] ? rg - a0 : help * m->mps_sy[0];
+                const uint32_t w1 = m->mps_is_top[1] ? rg - a1 : help * m->mps_sy[1];
+                const uint32_t in0 = lw - a0 < w0, in1 = lw - a1 < w1;
+                if (__builtin_expect(opaque_u32(in0 | in1), 1)) {
+                    hit = true;
+                    c = select_u32(in0, m->mps[0], m->mps[1]);
+                    lw -= select_u32(in0, a0, a1);
+                    rg = select_u32(in0, w0, w1);
+                }
+            }
+            if (!hit) {
+                const uint32_t cf = lw / help;
+                if (m->use_buckets) {
+                    const uint32_t e = m->bucket[cf >> kBucketShift];
+                    c = e;
+                    if (__builtin_expect(e == kMixed, 0)) c = m->lookup[cf];
+                } else
+                    c = m->lookup[cf];
+                const uint32_t t = help * m->tab[c].lt;
+                lw -= t;
+                rg = (c != m->top) ? help * m->tab[c].sy : rg - t;
+            }
+            dst[k][i] = (uint8_t)c;
+            low[k] = lw; range[k] = rg; p[k] = q;
+        }
+    }
+    for (int k = 0; k < NS; k++) { ds[k]->low = low[k]; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
+}
+
 using MultiFn = void (*)(Dec* const*, uint8_t* const*, const BlockModel* const*);
 template <int NS, unsigned... M>
 constexpr MultiFn multi_entry(unsigned mask, std::integer_sequence<unsigned, M...>)
@@ -557,84 +672,134 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
     case 1: multi_entry<1>(mask, std::make_integer_sequence<unsigned, 2>())(ds, dst, ms); break;
     case 2: multi_entry<2>(mask, std::make_integer_sequence<unsigned, 4>())(ds, dst, ms); break;
     case 3: multi_entry<3>(mask, std::make_integer_sequence<unsigned, 8>())(ds, dst, ms); break;
-    default: multi_entry<4>(mask, std::make_integer_sequence<unsigned, 16>())(ds, dst, ms); break;
+    case 4: multi_entry<4>(mask, std::make_integer_sequence<unsigned, 16>())(ds, dst, ms); break;
+    case 5: decode_symbols_multi_rt<5>(ds, dst, ms); break;
+    default: decode_symbols_multi_rt<6>(ds, dst, ms); break;
     }
 }
 
 }  // namespace
 
-void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced)
-{
-    // wrappers.cpp:153-224, the planes advancing block by block in lockstep
-    if (count < 1) return;
-    if (count > kMaxStreams) {
-        decode_planes(kMaxStreams, in, len, sym, n, produced);
-        decode_planes(count - kMaxStreams, in + kMaxStreams, len + kMaxStreams, sym + kMaxStreams, n, produced + kMaxStreams);
-        return;
+namespace {
+
+// A set of up to kMaxDecStreams plane streams advancing block by block in lockstep on one thread
+// (wrappers.cpp:153-224 per stream).  Streams join at any block boundary and leave when they end.
+class DecGroup {
+public:
+    explicit DecGroup(int cap) : cap_(cap < 1 ? 1 : (cap > kMaxDecStreams ? kMaxDecStreams : cap)), models_((size_t)cap_)
+    {
+        for (int k = 0; k < cap_; k++) ms_[k] = &models_[k];
     }
-    Dec* ds[kMaxStreams];
-    alignas(Dec) unsigned char store[kMaxStreams][sizeof(Dec)];
-    std::vector<BlockModel> models((size_t)count);
-    const BlockModel* ms[kMaxStreams];
-    bool live[kMaxStreams], failed[kMaxStreams];
-    uint8_t* dst[kMaxStreams];
-    std::vector<uint8_t> tails[kMaxStreams];
-    constexpr size_t kMargin = 3 * (size_t)kBlock + 8;  // a symbol pulls in at most 3 bytes
-    for (int k = 0; k < count; k++) {
-        ds[k] = new (store[k]) Dec(in[k], len[k]);
-        ms[k] = &models[k];
-        produced[k] = 0;
-        live[k] = true; failed[k] = false;
+    int count() const { return count_; }
+    bool full() const { return count_ == cap_; }
+    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag)
+    {
+        const int k = count_++;
+        ds_[k] = new (store_[k]) Dec(in, len);
+        sym_[k] = sym; n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
+        tails_[k].clear();
     }
-    for (;;) {
-        int nlive = 0;
+    // one block of every stream; on_end(tag, symbols the stream held or (size_t)-1) for the streams that ended
+    template <class OnEnd>
+    void step(OnEnd on_end)
+    {
+        constexpr size_t kMargin = 3 * (size_t)kBlock + 8;  // a symbol pulls in at most 3 bytes
         bool fast = true;
-        for (int k = 0; k < count; k++) {
-            if (!live[k]) { fast = false; continue; }
-            Dec& d = *ds[k];
-            BlockModel& m = models[k];
-            if (!d.culfreq(2)) { live[k] = false; fast = false; d.renorm(); continue; }  // done_decoding, rangecod.c:371-373
-            d.update(1, 1, 2);
-            uint32_t bs = 0, top_sym = 0;
-            for (int b = 0; b < 256; b++) {
-                uint32_t c = d.culshift(16) & 0xffffu;  // decode_short, rangecod.c:362-366
-                d.update(1, c, 1u << 16);
-                m.tab[b].lt = bs; m.tab[b].sy = c;
-                bs += c;
-                if (c) top_sym = (uint32_t)b;
+        for (int k = 0; k < count_;) {
+            Dec& d = *ds_[k];
+            BlockModel& m = *ms_[k];
+            bool ended = false;
+            if (!d.culfreq(2)) { d.renorm(); ended = true; }  // done_decoding, rangecod.c:371-373
+            else {
+                d.update(1, 1, 2);
+                uint32_t bs = 0, top_sym = 0;
+                for (int b = 0; b < 256; b++) {
+                    uint32_t c = d.culshift(16) & 0xffffu;  // decode_short, rangecod.c:362-366
+                    d.update(1, c, 1u << 16);
+                    m.tab[b].lt = bs; m.tab[b].sy = c;
+                    bs += c;
+                    if (c) top_sym = (uint32_t)b;
+                }
+                if (bs > kBlock) { failed_[k] = true; ended = true; }  // not a WaveRange stream (defs.h:36)
+                else {
+                    m.top = top_sym; m.bs = bs;
+                    finish_model(m);
+                }
             }
-            if (bs > kBlock) { live[k] = false; failed[k] = true; fast = false; continue; }  // not a WaveRange stream (defs.h:36)
-            m.top = top_sym; m.bs = bs;
-            finish_model(m);
-            dst[k] = sym[k] + (produced[k] < n ? produced[k] : n);
-            nlive++;
-            if (d.pos + kMargin > d.len && tails[k].empty() && d.pos >= 1 && d.pos <= d.len) {
+            if (ended) { retire(k, on_end); continue; }
+            dst_[k] = sym_[k] + (produced_[k] < n_[k] ? produced_[k] : n_[k]);
+            if (d.pos + kMargin > d.len && tails_[k].empty() && d.pos >= 1 && d.pos <= d.len) {
                 // near the end of the stream: continue on a zero-padded copy of the rest (reading past
                 // the end yields zeros, Dec::get), so that the unchecked loop stays usable
-                tails[k].assign(d.len - (d.pos - 1) + kMargin, 0);
-                memcpy(tails[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
-                d.in = tails[k].data(); d.len = tails[k].size(); d.pos = 1;
+                tails_[k].assign(d.len - (d.pos - 1) + kMargin, 0);
+                memcpy(tails_[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
+                d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
             }
-            if (bs != kBlock || produced[k] + kBlock > n || d.pos + kMargin > d.len) fast = false;
+            if (m.bs != kBlock || produced_[k] + kBlock > n_[k] || d.pos + kMargin > d.len) fast = false;
+            k++;
         }
-        if (!nlive) break;
+        if (!count_) return;
         if (fast) {
-            decode_block_multi(count, ds, dst, ms);
-            for (int k = 0; k < count; k++) produced[k] += kBlock;
-            continue;
+            decode_block_multi(count_, ds_, dst_, ms_);
+            for (int k = 0; k < count_; k++) produced_[k] += kBlock;
+            return;
         }
-        for (int k = 0; k < count; k++) {
-            if (!live[k]) continue;
-            const BlockModel& m = models[k];
-            const size_t room = produced[k] < n ? n - produced[k] : 0;
-            if (m.bs == kBlock) decode_symbols<kBlock>(*ds[k], dst[k], room, m.bs, m.tab, m.lookup, m.top);
-            else if (m.bs) decode_symbols<0>(*ds[k], dst[k], room, m.bs, m.tab, m.lookup, m.top);
-            produced[k] += m.bs;
-            if (ds[k]->pos > ds[k]->len + 8) { live[k] = false; failed[k] = true; }  // ran far past the end: corrupt stream
+        for (int k = 0; k < count_;) {
+            const BlockModel& m = *ms_[k];
+            const size_t room = produced_[k] < n_[k] ? n_[k] - produced_[k] : 0;
+            if (m.bs == kBlock) decode_symbols<kBlock>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
+            else if (m.bs) decode_symbols<0>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
+            produced_[k] += m.bs;
+            if (ds_[k]->pos > ds_[k]->len + 8) { failed_[k] = true; retire(k, on_end); continue; }  // ran far past the end: corrupt stream
+            k++;
         }
     }
-    for (int k = 0; k < count; k++)
-        if (failed[k]) produced[k] = (size_t)-1;
+
+private:
+    template <class OnEnd>
+    void retire(int k, OnEnd on_end)
+    {
+        on_end(tag_[k], failed_[k] ? (size_t)-1 : produced_[k]);
+        const int last = --count_;
+        if (k != last) {  // the last slot moves into the hole
+            ds_[k] = new (store_[k]) Dec(*ds_[last]);
+            std::swap(ms_[k], ms_[last]);
+            sym_[k] = sym_[last]; n_[k] = n_[last]; produced_[k] = produced_[last]; failed_[k] = failed_[last]; tag_[k] = tag_[last];
+            dst_[k] = dst_[last];
+            // Dec may point into its tail copy: the vector's buffer moves with it
+            tails_[k].swap(tails_[last]);
+        }
+        tails_[last].clear();
+    }
+
+    int cap_, count_ = 0;
+    std::vector<BlockModel> models_;
+    BlockModel* ms_[kMaxDecStreams];
+    Dec* ds_[kMaxDecStreams];
+    alignas(Dec) unsigned char store_[kMaxDecStreams][sizeof(Dec)];
+    uint8_t* sym_[kMaxDecStreams];
+    uint8_t* dst_[kMaxDecStreams];
+    size_t n_[kMaxDecStreams], produced_[kMaxDecStreams];
+    bool failed_[kMaxDecStreams];
+    void* tag_[kMaxDecStreams];
+    std::vector<uint8_t> tails_[kMaxDecStreams];
+};
+
+}  // namespace
+
+void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced)
+{
+    // up to kMaxStreams planes at a time in one symbol loop; further planes join as earlier ones end
+    DecGroup g(kMaxStreams);
+    int next = 0;
+    while (next < count || g.count()) {
+        while (next < count && !g.full()) {
+            produced[next] = 0;
+            g.add(in[next], len[next], sym[next], n, produced + next);
+            next++;
+        }
+        g.step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
+    }
 }
 
 size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
@@ -642,6 +807,128 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
     size_t produced = 0;
     decode_planes(1, &in, &len, &sym, n, &produced);
     return produced;
+}
+
+// =====================================================================================
+// Process-wide coder pool
+// =====================================================================================
+namespace {
+
+class Pool {
+public:
+    static Pool& get() { static Pool p; return p; }
+
+    int threads()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return (int)workers_.size();
+    }
+    void resize(int nthreads, int dec_streams)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (dec_streams >= 1) dec_streams_ = dec_streams > kMaxDecStreams ? kMaxDecStreams : dec_streams;
+        if (nthreads < 0) nthreads = 0;
+        if (nthreads == (int)workers_.size()) return;
+        // stop the present workers (they finish what they hold and what is queued), then start the new set
+        std::vector<std::thread> old;
+        old.swap(workers_);
+        stop_ = true;
+        cv_.notify_all();
+        lk.unlock();
+        for (auto& t : old) t.join();
+        lk.lock();
+        stop_ = false;
+        for (int i = 0; i < nthreads; i++) workers_.emplace_back([this] { run(); });
+    }
+    void submit(PlaneJob* jobs, int count, JobBatch* batch)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (int i = 0; i < count; i++) {
+            jobs[i].batch = batch;
+            (jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
+        }
+        { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
+        if (count > 1) cv_.notify_all(); else cv_.notify_one();
+    }
+    ~Pool() { resize(0, 0); }
+
+private:
+    PlaneJob* pop(bool block, int want)  // want: PlaneJob::Kind, or -1 for whatever is queued longest... decode first
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            if (want != PlaneJob::kEncode && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); return j; }
+            if (want != PlaneJob::kDecode && !enc_q_.empty()) { PlaneJob* j = enc_q_.front(); enc_q_.pop_front(); return j; }
+            if (!block || stop_) return nullptr;
+            cv_.wait(lk);
+        }
+    }
+    static void finish(PlaneJob* j, size_t result, double t0)
+    {
+        j->result = result;
+        j->seconds = now_s() - t0;
+        JobBatch* b = j->batch;
+        std::lock_guard<std::mutex> lk(b->mu);
+        if (--b->remaining == 0) b->cv.notify_all();
+    }
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void run()
+    {
+        int dec_streams;
+        { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
+        std::unique_ptr<DecGroup> dg;
+        EncGroup eg;
+        struct Tag { PlaneJob* job; double t0; };
+        Tag tags[kMaxDecStreams > kMaxEncStreams ? kMaxDecStreams : kMaxEncStreams];
+        for (;;) {
+            PlaneJob* j = pop(true, -1);
+            if (!j) return;
+            auto free_tag = [&]() -> Tag* { for (Tag& t : tags) if (!t.job) return &t; return nullptr; };
+            for (Tag& t : tags) t.job = nullptr;
+            if (j->kind == PlaneJob::kDecode) {
+                if (!dg) dg.reset(new DecGroup(dec_streams));
+                while (j || dg->count()) {
+                    while (j) {
+                        Tag* t = free_tag();
+                        t->job = j; t->t0 = now_s();
+                        dg->add(j->src, j->src_len, j->dst, j->n, t);
+                        j = dg->full() ? nullptr : pop(false, PlaneJob::kDecode);
+                    }
+                    dg->step([](void* tag, size_t got) { Tag* t = static_cast<Tag*>(tag); finish(t->job, got, t->t0); t->job = nullptr; });
+                    if (!dg->full()) j = pop(false, PlaneJob::kDecode);
+                }
+            } else {
+                while (j || eg.count()) {
+                    while (j) {
+                        Tag* t = free_tag();
+                        t->job = j; t->t0 = now_s();
+                        eg.add(j->src, j->n, j->dst, j->hist, t);
+                        j = eg.full() ? nullptr : pop(false, PlaneJob::kEncode);
+                    }
+                    eg.step([](void* tag, size_t len) { Tag* t = static_cast<Tag*>(tag); finish(t->job, len, t->t0); t->job = nullptr; });
+                    if (!eg.full()) j = pop(false, PlaneJob::kEncode);
+                }
+            }
+        }
+    }
+
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<PlaneJob*> enc_q_, dec_q_;
+    std::vector<std::thread> workers_;
+    bool stop_ = false;
+    int dec_streams_ = 6;
+};
+
+}  // namespace
+
+void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
+int pool_threads() { return Pool::get().threads(); }
+void pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { Pool::get().submit(jobs, count, batch); }
+void pool_wait(JobBatch* batch)
+{
+    std::unique_lock<std::mutex> lk(batch->mu);
+    batch->cv.wait(lk, [&] { return batch->remaining == 0; });
 }
 
 }  // namespace wrrc

@@ -9,10 +9,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <condition_variable>
+#include <mutex>
+
 namespace wrrc {
 
 constexpr uint32_t kBlock = 60000;  // reference src/core/defs.h:36
-constexpr int kMaxStreams = 4;      // planes interleaved in one symbol loop
+constexpr int kMaxStreams = 4;      // planes interleaved in one symbol loop by encode_planes / decode_planes
+constexpr int kMaxDecStreams = 6;   // ... by a pool worker's decoder loop
 
 // upper bound on the stream length for n symbols
 size_t encode_bound(size_t n);
@@ -34,5 +38,31 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n);
 // `count` streams of n symbols each on the calling thread, interleaved like encode_planes;
 // produced[k] as decode_plane's return value, (size_t)-1 for a stream that is not decodable.
 void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced);
+
+// ---- process-wide coder pool: plane streams of ALL concurrent encode / decode calls are coded by a fixed set
+// of worker threads.  A worker interleaves up to 3 encoder or up to `dec_streams` (<= kMaxDecStreams) decoder
+// streams in one symbol loop, whichever fields they belong to; streams join at block boundaries as others
+// end.  (Per call there are only 3-4 planes: fewer than a decoder loop can keep in flight.)
+struct JobBatch {  // completion of a group of jobs (owned by the submitter)
+    std::mutex mu;
+    std::condition_variable cv;
+    int remaining = 0;
+};
+struct PlaneJob {
+    enum Kind { kEncode = 0, kDecode = 1 };
+    int kind = kEncode;
+    const uint8_t* src = nullptr;  // encode: n symbols; decode: the stream
+    size_t src_len = 0;            // decode: stream length
+    uint8_t* dst = nullptr;        // encode: encode_bound(n) bytes; decode: n symbols
+    size_t n = 0;
+    const uint16_t* hist = nullptr;  // encode: per-block histograms from the GPU, or null
+    size_t result = 0;             // encode: stream length; decode: symbols the stream held, (size_t)-1 if undecodable
+    double seconds = 0;            // from the moment a worker took the job to its end
+    JobBatch* batch = nullptr;
+};
+void pool_configure(int nthreads, int dec_streams);  // nthreads = 0 stops the pool; dec_streams < 1 keeps the setting
+int pool_threads();
+void pool_submit(PlaneJob* jobs, int count, JobBatch* batch);  // the jobs must stay valid until pool_wait returns
+void pool_wait(JobBatch* batch);
 
 }  // namespace wrrc
