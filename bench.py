@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="device work-space slots (0: library default)")
     ap.add_argument("--pool", type=int, default=-1, help="coder-pool worker threads shared by all fields in flight (-1: one per CPU of this rank; 0: no pool, "
                     "every call runs its own --threads coder threads)")
-    ap.add_argument("--dec-streams", type=int, default=6, help="plane streams a pool worker's decoder loop interleaves (1..6)")
+    ap.add_argument("--dec-streams", type=int, default=4, help="plane streams a pool worker's decoder loop interleaves (1..4)")
     args = ap.parse_args()
     tols = [float(t) for t in args.tols.split(",")]
     n = args.size

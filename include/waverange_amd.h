@@ -152,7 +152,7 @@ void wr_set_encoder_threads(int nthreads);
 /* Process-wide coder pool for callers that keep several fields in flight: nthreads > 0 starts that many worker
  * threads which code the plane streams of ALL concurrent encode / decode calls (wr_set_threads is then
  * ignored); 0 stops it (default: every call runs its own coder threads).  A worker interleaves up to 3 encoder
- * or decoder_streams (1..6, default 6; < 1 keeps the setting) decoder streams in one symbol loop, whichever
+ * or decoder_streams (1..4, default 4; < 1 keeps the setting) decoder streams in one symbol loop, whichever
  * fields they belong to, so a decoder loop is not limited to the 3-4 planes of one field, and the number of
  * running coder threads never exceeds nthreads.  Same bytes either way. */
 void wr_set_coder_pool(int nthreads, int decoder_streams);

@@ -41,7 +41,7 @@ for kinds in (["noise"], ["two"], ["one"], ["noise"] * 2, ["two"] * 2, ["noise"]
     print("%-28s encode %6.1f Msym/s   decode %6.1f Msym/s   (per thread, all planes of the group together)" % ("+".join(kinds), e, d), flush=True)
 
 
-# the coder pool with ONE worker: the same thread budget, but the worker's decoder loop takes up to 6 streams
+# the coder pool with ONE worker: the same thread budget, but the worker's decoder loop takes up to 4 streams of any fields
 def pool_rate(kinds, streams):
     ps = [plane(k) for k in kinds]
     api.set_coder_pool(1, streams)
@@ -53,7 +53,7 @@ def pool_rate(kinds, streams):
     return len(ps) * n / best_e / 1e6, len(ps) * n / best_d / 1e6
 
 
-for streams in (4, 5, 6):
+for streams in (3, 4):
     for kinds in (["two", "two", "noise", "noise"] * 3, ["noise"] * 12, ["two"] * 12, ["one", "two", "noise"] * 4):
         e, d = pool_rate(kinds, streams)
         print("pool, 1 worker, %d decoder streams, 12 planes %-22s encode %6.1f Msym/s   decode %6.1f Msym/s" % (streams, "+".join(kinds[:4]) + "..", e, d), flush=True)

@@ -589,74 +589,6 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
     for (int k = 0; k < NS; k++) { ds[k]->low = low[k]; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
 }
 
-// The same loop for more than four streams, with "this block has dominant symbols" tested at run time (the
-// branch has one outcome per stream for the whole block) instead of one instantiation per combination.
-template <int NS>
-void decode_symbols_multi_rt(Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
-{
-    uint32_t low[NS], range[NS];
-    const uint8_t* p[NS];
-    for (int k = 0; k < NS; k++) { low[k] = ds[k]->low; range[k] = ds[k]->range; p[k] = ds[k]->in + ds[k]->pos; }
-    for (uint32_t i = 0; i < kBlock; i++) {
-#pragma GCC unroll 8
-        for (int k = 0; k < NS; k++) {
-            const BlockModel* const m = ms[k];
-            uint32_t lw = low[k], rg = range[k];
-            const uint8_t* q = p[k];
-            {
-                const uint32_t sh = rg <= kBottom;
-                const uint32_t bits = ((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff;
-                lw = (lw << (8 * sh)) | (bits & (0u - sh));
-                rg <<= 8 * sh;
-                q += sh;
-            }
-            while (__builtin_expect(rg <= kBottom, 0)) {
-                lw = (lw << 8) | (((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff);
-                rg <<= 8;
-                q++;
-            }
-            const uint32_t help = rg / kBlock;
-            uint32_t c;
-            bool hit = false;
-            if (m->few) {
-                const uint32_t t1 = help * m->few_lt[1], t2 = help * m->few_lt[2], t3 = help * m->few_lt[3];
-                const uint32_t idx = (uint32_t)(lw >= t1) + (uint32_t)(lw >= t2) + (uint32_t)(lw >= t3);
-                const uint32_t t = select_u32(idx, select_u32(idx ^ 1, select_u32(idx ^ 2, t3, t2), t1), 0);
-                hit = true;
-                c = m->few_sym[idx];
-                lw -= t;
-                rg = select_u32(idx ^ (m->few - 1), help * m->few_sy[idx], rg - t);
-            } else if (m->mps_on) {
-                const uint32_t a0 = help * m->mps_lt[0], a1 = help * m->mps_lt[1];
-                const uint32_t w0 = m->mps_is_top[0] ? rg - a0 : help * m->mps_sy[0];
-                const uint32_t w1 = m->mps_is_top[1] ? rg - a1 : help * m->mps_sy[1];
-                const uint32_t in0 = lw - a0 < w0, in1 = lw - a1 < w1;
-                if (__builtin_expect(opaque_u32(in0 | in1), 1)) {
-                    hit = true;
-                    c = select_u32(in0, m->mps[0], m->mps[1]);
-                    lw -= select_u32(in0, a0, a1);
-                    rg = select_u32(in0, w0, w1);
-                }
-            }
-            if (!hit) {
-                const uint32_t cf = lw / help;
-                if (m->use_buckets) {
-                    const uint32_t e = m->bucket[cf >> kBucketShift];
-                    c = e;
-                    if (__builtin_expect(e == kMixed, 0)) c = m->lookup[cf];
-                } else
-                    c = m->lookup[cf];
-                const uint32_t t = help * m->tab[c].lt;
-                lw -= t;
-                rg = (c != m->top) ? help * m->tab[c].sy : rg - t;
-            }
-            dst[k][i] = (uint8_t)c;
-            low[k] = lw; range[k] = rg; p[k] = q;
-        }
-    }
-    for (int k = 0; k < NS; k++) { ds[k]->low = low[k]; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
-}
-
 using MultiFn = void (*)(Dec* const*, uint8_t* const*, const BlockModel* const*);
 template <int NS, unsigned... M>
 constexpr MultiFn multi_entry(unsigned mask, std::integer_sequence<unsigned, M...>)
@@ -672,9 +604,7 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
     case 1: multi_entry<1>(mask, std::make_integer_sequence<unsigned, 2>())(ds, dst, ms); break;
     case 2: multi_entry<2>(mask, std::make_integer_sequence<unsigned, 4>())(ds, dst, ms); break;
     case 3: multi_entry<3>(mask, std::make_integer_sequence<unsigned, 8>())(ds, dst, ms); break;
-    case 4: multi_entry<4>(mask, std::make_integer_sequence<unsigned, 16>())(ds, dst, ms); break;
-    case 5: decode_symbols_multi_rt<5>(ds, dst, ms); break;
-    default: decode_symbols_multi_rt<6>(ds, dst, ms); break;
+    default: multi_entry<4>(mask, std::make_integer_sequence<unsigned, 16>())(ds, dst, ms); break;
     }
 }
 
@@ -917,7 +847,7 @@ private:
     std::deque<PlaneJob*> enc_q_, dec_q_;
     std::vector<std::thread> workers_;
     bool stop_ = false;
-    int dec_streams_ = 6;
+    int dec_streams_ = kMaxDecStreams;
 };
 
 }  // namespace
