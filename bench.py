@@ -351,7 +351,8 @@ def main():
                                                  ("dec_wait_s", td["wait"]), ("enc_h2d_ms", te["h2d_ms"]), ("enc_d2h_ms", te["d2h_ms"]),
                                                  ("dec_h2d_ms", td["h2d_ms"]), ("dec_d2h_ms", td["d2h_ms"]), ("nlay", enc["nlay"])):
                                     acc[key].append(val)
-                                stats[ln["tol"]] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"]}
+                                stats[ln["tol"]] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"],
+                                                    "bits_per_symbol": [round(8.0 * v / nelem, 3) for v in enc["len_enc_vec"]]}
                 except Exception as exc:
                     errors.append(exc)
                     for sem in free:

@@ -63,6 +63,56 @@ int main() {
                 if (k != victim && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("healthy stream disturbed by a damaged one\n"); return 1; }
         }
     }
+    // the 16-lane AVX-512 loop (dominant-symbol planes) and the coder pool: 20 planes of mixed kinds and lengths,
+    // exact-size stream copies, damaged streams among healthy ones
+    {
+        const int count = 20;
+        std::vector<std::vector<uint8_t>> p(count), enc(count), back(count);
+        std::vector<const uint8_t*> ip(count);
+        std::vector<uint8_t*> bp(count);
+        std::vector<size_t> n(count), len(count), got(count);
+        for (int k = 0; k < count; k++) {
+            n[k] = (size_t)60000 * (5 + k % 4) + (k % 3) * 777;
+            p[k].resize(n[k]); back[k].resize(n[k]);
+            for (size_t i = 0; i < n[k]; i++) { unsigned r = rnd(); p[k][i] = k % 5 == 4 ? r & 255 : ((r & 7) ? 254 : 255 - (k % 2) * ((r >> 8 & 255) == 0 ? 200 : 0)); }
+            std::vector<uint8_t> out(wrrc::encode_bound(n[k]));
+            len[k] = wrrc::encode_plane(p[k].data(), n[k], out.data(), nullptr);
+            enc[k].assign(out.begin(), out.begin() + len[k]);
+            ip[k] = enc[k].data(); bp[k] = back[k].data();
+        }
+        if (wrrc::decode_planes_vec(count, ip.data(), len.data(), bp.data(), n.data(), got.data())) {
+            for (int k = 0; k < count; k++)
+                if (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k])) { printf("vector decode failed k=%d\n", k); return 1; }
+            for (int trial = 0; trial < 4; trial++) {
+                const int victim = (int)(rnd() % count);
+                std::vector<uint8_t> bad(enc[victim]);
+                if (trial < 2) bad.resize(bad.size() * (trial + 1) / 3);
+                else for (int j = 0; j < 16; j++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
+                std::vector<const uint8_t*> ip2(ip); std::vector<size_t> l2(len);
+                ip2[victim] = bad.data(); l2[victim] = bad.size();
+                wrrc::decode_planes_vec(count, ip2.data(), l2.data(), bp.data(), n.data(), got.data());
+                for (int k = 0; k < count; k++)
+                    if (k != victim && (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k]))) { printf("vector: healthy stream disturbed\n"); return 1; }
+            }
+        } else printf("(no AVX-512 here: vector loop not exercised)\n");
+        wrrc::pool_configure(3, 4);
+        std::vector<wrrc::PlaneJob> jobs(2 * count);
+        std::vector<std::vector<uint8_t>> out2(count), back2(count);
+        wrrc::JobBatch batch;
+        for (int k = 0; k < count; k++) {
+            out2[k].resize(wrrc::encode_bound(n[k])); back2[k].resize(n[k]);
+            jobs[k].kind = wrrc::PlaneJob::kEncode; jobs[k].src = p[k].data(); jobs[k].n = n[k]; jobs[k].dst = out2[k].data();
+            jobs[count + k].kind = wrrc::PlaneJob::kDecode; jobs[count + k].src = enc[k].data(); jobs[count + k].src_len = len[k];
+            jobs[count + k].dst = back2[k].data(); jobs[count + k].n = n[k];
+        }
+        wrrc::pool_submit(jobs.data(), 2 * count, &batch);
+        wrrc::pool_wait(&batch);
+        for (int k = 0; k < count; k++) {
+            if (jobs[k].result != len[k] || memcmp(out2[k].data(), enc[k].data(), len[k])) { printf("pool encode differs k=%d\n", k); return 1; }
+            if (jobs[count + k].result != n[k] || memcmp(back2[k].data(), p[k].data(), n[k])) { printf("pool decode failed k=%d\n", k); return 1; }
+        }
+        wrrc::pool_configure(0, 0);
+    }
     printf("range coder sanitizer run OK\n");
     return 0;
 }

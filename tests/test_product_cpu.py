@@ -245,3 +245,36 @@ def test_coder_pool_same_bytes_as_oracle(oracle):
         assert got[2] != good[2].size
     finally:
         api.set_coder_pool(0)
+
+
+def test_avx512_decoder_loop_same_symbols(oracle):
+    """The 16-lane AVX-512 decoder loop for dominant-symbol planes (wr_rangecoder_avx512.cpp): two-symbol planes with
+    the pair anywhere in the alphabet (incl. the largest symbol present, whose interval is open-ended), one
+    dominant symbol with rare others (scalar look-up on that lane), a noise plane (every block falls back to
+    the scalar loop), lengths around the block size, more planes than lanes.  Streams come from the oracle."""
+    from waverange_amd import api
+    rs = np.random.RandomState(3)
+    planes = []
+    for n in (1, 59999, 60000, 60001, 300000, 300123, 420000, 419999):
+        planes.append(rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.8, 0.2]))
+        planes.append(rs.choice(np.array([254, 255], np.uint8), size=n))
+        planes.append(rs.choice(np.array([0, 255], np.uint8), size=n, p=[0.05, 0.95]))
+        planes.append(np.where(rs.random_sample(n) < 0.9997, 128, rs.randint(120, 136, n)).astype(np.uint8))
+        planes.append(np.full(n, 9, np.uint8))
+    planes.append(rs.randint(0, 256, 300000).astype(np.uint8))
+    planes.append(rs.choice(np.array([3, 4, 5, 250], np.uint8), size=300000))
+    enc = [oracle.range_encode(p) for p in planes]
+    try:
+        dec, got = api.range_decode_vec(enc, [p.size for p in planes])
+    except api.WaveRangeError:
+        pytest.skip("no AVX-512 on this CPU")
+    for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+        assert g == p.size and np.array_equal(d, p), (i, p.size)
+    # through the pool as well (planes below 2 bits per symbol take the vector route there)
+    api.set_coder_pool(2, 4)
+    try:
+        dec, got = api.range_decode_pool(enc, [p.size for p in planes])
+        for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+            assert g == p.size and np.array_equal(d, p), ("pool", i, p.size)
+    finally:
+        api.set_coder_pool(0)

@@ -57,3 +57,18 @@ for streams in (3, 4):
     for kinds in (["two", "two", "noise", "noise"] * 3, ["noise"] * 12, ["two"] * 12, ["one", "two", "noise"] * 4):
         e, d = pool_rate(kinds, streams)
         print("pool, 1 worker, %d decoder streams, 12 planes %-22s encode %6.1f Msym/s   decode %6.1f Msym/s" % (streams, "+".join(kinds[:4]) + "..", e, d), flush=True)
+
+
+# the 16-lane AVX-512 loop for dominant-symbol planes (one thread)
+for k in (4, 8, 12, 16):
+    for kind in ("two", "one"):
+        ps = [plane(kind) for _ in range(k)]
+        ss = [api.range_encode(p) for p in ps]
+        best = 1e9
+        try:
+            for _ in range(3):
+                t = time.time(); api.range_decode_vec(ss, [n] * k); best = min(best, time.time() - t)
+            print("AVX-512 loop, %2d planes of kind %-4s decode %7.1f Msym/s per thread" % (k, kind, k * n / best / 1e6), flush=True)
+        except api.WaveRangeError as exc:
+            print("AVX-512 loop:", exc)
+            break

@@ -127,6 +127,7 @@ def lib():
     L.wr_range_decode_multi.argtypes = [C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]
     L.wr_range_encode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_range_decode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.wr_range_decode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_bench_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     # drop-in symbols (reference src/core/wrappers.h:53,70,75)
     L.setup_wr.argtypes = [C.c_int] * 3 + [_u8p, _ulp]
@@ -258,6 +259,17 @@ def range_decode_pool(streams, ns):
     got = (C.c_size_t * k)()
     _check(lib().wr_range_decode_pool(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
                                       (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*ns), got))
+    return [o[:n] for o, n in zip(outs, ns)], [got[i] for i in range(k)]
+
+
+def range_decode_vec(streams, ns):
+    """Planes through the 16-lane AVX-512 decoder loop on this thread (raises on CPUs without AVX-512)."""
+    ss = [np.ascontiguousarray(s, dtype=np.uint8).ravel() for s in streams]
+    k = len(ss)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for n in ns]
+    got = (C.c_size_t * k)()
+    _check(lib().wr_range_decode_vec(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
+                                     (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*ns), got))
     return [o[:n] for o, n in zip(outs, ns)], [got[i] for i in range(k)]
 
 

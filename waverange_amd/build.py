@@ -16,7 +16,9 @@ LIB = os.path.join(HERE, "libwaverange_amd.so")
 ALIAS = os.path.join(HERE, "libwaverange.so")  # the reference's library name (drop-in link target)
 BIN = os.path.join(HERE, "bin")
 
-SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_dma.cpp", "wr_rangecoder.cpp", "wr_compat.cpp"]
+SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_dma.cpp", "wr_rangecoder.cpp", "wr_rangecoder_avx512.cpp", "wr_compat.cpp"]
+# per-file extra flags: the AVX-512 coder loop is only entered when the CPU has the instructions (vec_available)
+EXTRA = {"wr_rangecoder_avx512.cpp": ["-mavx512f", "-mavx512bw", "-mavx512dq", "-mavx512vl"]}
 CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"],
        # MSSG front-end (GrADS regular output, restart sets united / divided)
        "wrenc_mssg": ["cli/mssg_enc.cpp", "cli/mssg_io.cpp"], "wrdec_mssg": ["cli/mssg_dec.cpp", "cli/mssg_io.cpp"]}
@@ -55,7 +57,7 @@ def build(force=False, verbose=True):
         os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
         for s in SOURCES:
             o = os.path.join(HERE, "build", s.replace("/", "_") + ".o")
-            cmd = [hipcc] + COMMON + os.environ.get("WR_CXXFLAGS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
+            cmd = [hipcc] + COMMON + EXTRA.get(s, []) + os.environ.get("WR_CXXFLAGS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -1454,6 +1454,13 @@ void wr_range_decode_multi(int count, const unsigned char* const* in, const size
     wrrc::decode_planes(count, in, len, sym, n, produced);
 }
 
+int wr_range_decode_vec(int count, const unsigned char* const* in, const size_t* len, unsigned char* const* sym, const size_t* n,
+                        size_t* produced)
+{
+    if (!wrrc::decode_planes_vec(count, in, len, sym, n, produced)) return fail(WR_ERR_UNSUPPORTED, "this CPU has no AVX-512");
+    return WR_OK;
+}
+
 int wr_range_encode_pool(int count, const unsigned char* const* sym, const size_t* n, unsigned char* const* out, size_t* lens)
 {
     if (wrrc::pool_threads() < 1) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");

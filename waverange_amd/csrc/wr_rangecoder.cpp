@@ -9,6 +9,7 @@
 //     symbols (all but the last) use a compile-time divisor so range/tot is a multiply;
 //   * no intermediate copies (wrappers.cpp:119-121,137-139 copy every byte twice).
 #include "wr_rangecoder.h"
+#include "wr_rangecoder_vec.h"
 
 #include <string.h>
 
@@ -464,6 +465,7 @@ struct BlockModel {
     // planes stays in L1, the four 60 KB lookup tables do not.  Used when < 2 % of the block
     // falls into mixed buckets (each escape is a branch miss).
     bool use_buckets;
+    bool tables_ready;  // bucket / lookup are filled in (the vector loop builds them only when a rare symbol turns up)
     uint16_t bucket[kBuckets];
     uint8_t lookup[kBlock + kPad];
 };
@@ -475,11 +477,27 @@ constexpr uint16_t kMixed = 0x100;
 #define WR_RC_MPS_PCT 90
 #endif
 
-void finish_model(BlockModel& m)
+// the look-up side of a block model (60 KB + buckets): what the division path needs
+void finish_model_tables(BlockModel& m)
 {
     for (int b = 0; b < 256; b++)
         if (m.tab[b].sy) memset(m.lookup + m.tab[b].lt, b, m.tab[b].sy);
     memset(m.lookup + m.bs, (int)m.top, kPad);
+    uint32_t mixed = 0;
+    for (uint32_t j = 0; j < kBuckets; j++) {
+        const uint32_t lo = j << kBucketShift, hi = lo + (1u << kBucketShift) - 1;
+        const uint8_t a = m.lookup[lo < kBlock + kPad ? lo : kBlock + kPad - 1], z = m.lookup[hi < kBlock + kPad ? hi : kBlock + kPad - 1];
+        m.bucket[j] = (a == z) ? a : kMixed;  // symbols ascend with the cumulative frequency: equal ends = equal throughout
+        if (a != z && lo < m.bs) mixed += 1u << kBucketShift;
+    }
+    m.use_buckets = (uint64_t)mixed * 100 < (uint64_t)m.bs * WR_RC_MIXED_PCT;
+    m.tables_ready = true;
+}
+
+// the cheap side: dominant symbols, few-symbol form
+void finish_model_stats(BlockModel& m)
+{
+    m.tables_ready = false;
     uint32_t b1 = 0, b2 = 256;
     for (int b = 1; b < 256; b++)
         if (m.tab[b].sy > m.tab[b1].sy) b1 = (uint32_t)b;
@@ -499,14 +517,12 @@ void finish_model(BlockModel& m)
     m.few = (!m.mps_on && distinct >= 3 && distinct <= 4) ? distinct : 0;
     for (uint32_t j = distinct; j < 4; j++) { m.few_sym[j] = m.top; m.few_lt[j] = 0xffff; m.few_sy[j] = 0; }  // help * 0xffff > low, always
     if (m.few) m.mps_on = true;
-    uint32_t mixed = 0;
-    for (uint32_t j = 0; j < kBuckets; j++) {
-        const uint32_t lo = j << kBucketShift, hi = lo + (1u << kBucketShift) - 1;
-        const uint8_t a = m.lookup[lo < kBlock + kPad ? lo : kBlock + kPad - 1], z = m.lookup[hi < kBlock + kPad ? hi : kBlock + kPad - 1];
-        m.bucket[j] = (a == z) ? a : kMixed;  // symbols ascend with the cumulative frequency: equal ends = equal throughout
-        if (a != z && lo < m.bs) mixed += 1u << kBucketShift;
-    }
-    m.use_buckets = (uint64_t)mixed * 100 < (uint64_t)m.bs * WR_RC_MIXED_PCT;
+}
+
+void finish_model(BlockModel& m)
+{
+    finish_model_stats(m);
+    finish_model_tables(m);
 }
 
 // Symbol loop of NS planes, interleaved; needs, per plane, a full block, room for 60000 symbols
@@ -717,6 +733,163 @@ private:
 
 }  // namespace
 
+namespace {
+
+// a symbol outside the two dominant ones, for one lane of the vector loop: the look-up path of decode_symbols
+uint32_t vec_other_symbol(const void* model, uint32_t* low, uint32_t* range, uint32_t help)
+{
+    BlockModel& m = *const_cast<BlockModel*>(static_cast<const BlockModel*>(model));
+    if (!m.tables_ready) finish_model_tables(m);
+    const uint32_t cf = *low / help;
+    const uint32_t c = m.lookup[cf];
+    const uint32_t t = help * m.tab[c].lt;
+    *low -= t;
+    *range = (c != m.top) ? help * m.tab[c].sy : *range - t;
+    return c;
+}
+
+// Up to 16 plane streams whose blocks mostly hold two dominant symbols, advancing block by block in lockstep on
+// one thread: the blocks of that kind are decoded 16 lanes at a time by the AVX-512 loop, the occasional other
+// block by the scalar loop of its stream.
+class VecDecGroup {
+public:
+    static constexpr int kCap = kVecLanes;
+    VecDecGroup() : models_((size_t)kCap) { for (int k = 0; k < kCap; k++) ms_[k] = &models_[k]; }
+    int count() const { return count_; }
+    bool full() const { return count_ == kCap; }
+    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag)
+    {
+        const int k = count_++;
+        ds_[k] = new (store_[k]) Dec(in, len);
+        sym_[k] = sym; n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
+        tails_[k].clear();
+    }
+    template <class OnEnd>
+    void step(OnEnd on_end)
+    {
+        constexpr size_t kMargin = 3 * (size_t)kBlock + 8;
+        bool vec[kCap];
+        for (int k = 0; k < count_;) {
+            Dec& d = *ds_[k];
+            BlockModel& m = *ms_[k];
+            bool ended = false;
+            if (!d.culfreq(2)) { d.renorm(); ended = true; }
+            else {
+                d.update(1, 1, 2);
+                uint32_t bs = 0, top_sym = 0;
+                for (int b = 0; b < 256; b++) {
+                    uint32_t c = d.culshift(16) & 0xffffu;
+                    d.update(1, c, 1u << 16);
+                    m.tab[b].lt = bs; m.tab[b].sy = c;
+                    bs += c;
+                    if (c) top_sym = (uint32_t)b;
+                }
+                if (bs > kBlock) { failed_[k] = true; ended = true; }
+                else { m.top = top_sym; m.bs = bs; finish_model_stats(m); }
+            }
+            if (ended) { retire(k, on_end); continue; }
+            dst_[k] = sym_[k] + (produced_[k] < n_[k] ? produced_[k] : n_[k]);
+            if (d.pos + kMargin > d.len && tails_[k].empty() && d.pos >= 1 && d.pos <= d.len) {
+                tails_[k].assign(d.len - (d.pos - 1) + kMargin, 0);
+                memcpy(tails_[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
+                d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
+            }
+            const bool fast = m.bs == kBlock && produced_[k] + kBlock <= n_[k] && d.pos + kMargin <= d.len;
+            vec[k] = fast && m.mps_on && !m.few;
+            k++;
+        }
+        if (!count_) return;
+        VecBlock vb;
+        vb.active = 0;
+        for (int k = 0; k < count_; k++) {
+            if (!vec[k]) continue;
+            const Dec& d = *ds_[k];
+            const BlockModel& m = *ms_[k];
+            vb.active |= 1u << k;
+            vb.low[k] = d.low; vb.range[k] = d.range; vb.ptr[k] = d.in + d.pos; vb.dst[k] = dst_[k];
+            for (int e = 0; e < 2; e++) {
+                vb.lt[e][k] = m.mps_lt[e]; vb.sy[e][k] = m.mps_sy[e]; vb.is_top[e][k] = m.mps_is_top[e]; vb.sym[e][k] = m.mps[e];
+            }
+            vb.model[k] = &m;
+        }
+        if (vb.active) {
+            for (int k = 0; k < kCap; k++) if (!(vb.active >> k & 1)) { vb.is_top[0][k] = vb.is_top[1][k] = 0; vb.ptr[k] = nullptr; vb.dst[k] = nullptr; }
+            vec_decode_two_symbol_block(&vb, vec_other_symbol);
+            for (int k = 0; k < count_; k++) {
+                if (!vec[k]) continue;
+                Dec& d = *ds_[k];
+                d.low = vb.low[k]; d.range = vb.range[k]; d.pos = (size_t)(vb.ptr[k] - d.in); d.held = vb.ptr[k][-1];
+                produced_[k] += kBlock;
+            }
+        }
+        for (int k = 0; k < count_;) {
+            if (vec[k]) { k++; continue; }
+            BlockModel& m = *ms_[k];
+            if (!m.tables_ready) finish_model_tables(m);
+            const size_t room = produced_[k] < n_[k] ? n_[k] - produced_[k] : 0;
+            if (m.bs == kBlock) decode_symbols<kBlock>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
+            else if (m.bs) decode_symbols<0>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
+            produced_[k] += m.bs;
+            if (ds_[k]->pos > ds_[k]->len + 8) {
+                failed_[k] = true;
+                const int last = count_ - 1;
+                retire(k, on_end);
+                if (k != last) vec[k] = vec[last];  // the slot that moved in: done already if it was a vector lane
+                continue;
+            }
+            k++;
+        }
+    }
+
+private:
+    template <class OnEnd>
+    void retire(int k, OnEnd on_end)
+    {
+        on_end(tag_[k], failed_[k] ? (size_t)-1 : produced_[k]);
+        const int last = --count_;
+        if (k != last) {
+            ds_[k] = new (store_[k]) Dec(*ds_[last]);
+            std::swap(ms_[k], ms_[last]);
+            sym_[k] = sym_[last]; n_[k] = n_[last]; produced_[k] = produced_[last]; failed_[k] = failed_[last]; tag_[k] = tag_[last];
+            dst_[k] = dst_[last];
+            tails_[k].swap(tails_[last]);
+        }
+        tails_[last].clear();
+    }
+
+    int count_ = 0;
+    std::vector<BlockModel> models_;
+    BlockModel* ms_[kCap];
+    Dec* ds_[kCap];
+    alignas(Dec) unsigned char store_[kCap][sizeof(Dec)];
+    uint8_t* sym_[kCap];
+    uint8_t* dst_[kCap];
+    size_t n_[kCap], produced_[kCap];
+    bool failed_[kCap];
+    void* tag_[kCap];
+    std::vector<uint8_t> tails_[kCap];
+};
+
+}  // namespace
+
+// `count` streams of dominant-symbol planes (any lengths) on the calling thread through the 16-lane loop: test
+// and measurement hook; the coder pool is the product path.  False if the CPU lacks AVX-512.
+bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced)
+{
+    if (!vec_available()) return false;
+    std::unique_ptr<VecDecGroup> g(new VecDecGroup);
+    int next = 0;
+    while (next < count || g->count()) {
+        while (next < count && !g->full()) {
+            produced[next] = 0;
+            g->add(in[next], len[next], sym[next], n[next], produced + next);
+            next++;
+        }
+        g->step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
+    }
+    return true;
+}
+
 void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced)
 {
     // up to kMaxStreams planes at a time in one symbol loop; further planes join as earlier ones end
@@ -775,7 +948,10 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         for (int i = 0; i < count; i++) {
             jobs[i].batch = batch;
-            (jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
+            // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
+            const bool vec = jobs[i].kind == PlaneJob::kDecode && vec_ok_ && jobs[i].n >= 4 * (size_t)kBlock &&
+                             8 * jobs[i].src_len < 2 * jobs[i].n;
+            (vec ? vec_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
         if (count > 1) cv_.notify_all(); else cv_.notify_one();
@@ -783,12 +959,15 @@ public:
     ~Pool() { resize(0, 0); }
 
 private:
-    PlaneJob* pop(bool block, int want)  // want: PlaneJob::Kind, or -1 for whatever is queued longest... decode first
+    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2 };
+    // kAny: vector-decode jobs first (one worker absorbs up to 16 of them), then decode, then encode
+    PlaneJob* pop(bool block, int want, int* got = nullptr)
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            if (want != PlaneJob::kEncode && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); return j; }
-            if (want != PlaneJob::kDecode && !enc_q_.empty()) { PlaneJob* j = enc_q_.front(); enc_q_.pop_front(); return j; }
+            if ((want == kAny || want == kVec) && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); if (got) *got = kVec; return j; }
+            if ((want == kAny || want == kDec) && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); if (got) *got = kDec; return j; }
+            if ((want == kAny || want == kEnc) && !enc_q_.empty()) { PlaneJob* j = enc_q_.front(); enc_q_.pop_front(); if (got) *got = kEnc; return j; }
             if (!block || stop_) return nullptr;
             cv_.wait(lk);
         }
@@ -807,25 +986,41 @@ private:
         int dec_streams;
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
         std::unique_ptr<DecGroup> dg;
+        std::unique_ptr<VecDecGroup> vg;
         EncGroup eg;
         struct Tag { PlaneJob* job; double t0; };
-        Tag tags[kMaxDecStreams > kMaxEncStreams ? kMaxDecStreams : kMaxEncStreams];
+        Tag tags[kVecLanes];
+        auto free_tag = [&]() -> Tag* { for (Tag& t : tags) if (!t.job) return &t; return nullptr; };
+        auto on_end = [](void* tag, size_t result) { Tag* t = static_cast<Tag*>(tag); finish(t->job, result, t->t0); t->job = nullptr; };
         for (;;) {
-            PlaneJob* j = pop(true, -1);
+            int kind = kAny;
+            PlaneJob* j = pop(true, kAny, &kind);
             if (!j) return;
-            auto free_tag = [&]() -> Tag* { for (Tag& t : tags) if (!t.job) return &t; return nullptr; };
             for (Tag& t : tags) t.job = nullptr;
-            if (j->kind == PlaneJob::kDecode) {
+            // a session: the streams of one kind this worker interleaves, topped up at block boundaries
+            if (kind == kVec) {
+                if (!vg) vg.reset(new VecDecGroup);
+                while (j || vg->count()) {
+                    while (j) {
+                        Tag* t = free_tag();
+                        t->job = j; t->t0 = now_s();
+                        vg->add(j->src, j->src_len, j->dst, j->n, t);
+                        j = vg->full() ? nullptr : pop(false, kVec);
+                    }
+                    vg->step(on_end);
+                    if (!vg->full()) j = pop(false, kVec);
+                }
+            } else if (kind == kDec) {
                 if (!dg) dg.reset(new DecGroup(dec_streams));
                 while (j || dg->count()) {
                     while (j) {
                         Tag* t = free_tag();
                         t->job = j; t->t0 = now_s();
                         dg->add(j->src, j->src_len, j->dst, j->n, t);
-                        j = dg->full() ? nullptr : pop(false, PlaneJob::kDecode);
+                        j = dg->full() ? nullptr : pop(false, kDec);
                     }
-                    dg->step([](void* tag, size_t got) { Tag* t = static_cast<Tag*>(tag); finish(t->job, got, t->t0); t->job = nullptr; });
-                    if (!dg->full()) j = pop(false, PlaneJob::kDecode);
+                    dg->step(on_end);
+                    if (!dg->full()) j = pop(false, kDec);
                 }
             } else {
                 while (j || eg.count()) {
@@ -833,10 +1028,10 @@ private:
                         Tag* t = free_tag();
                         t->job = j; t->t0 = now_s();
                         eg.add(j->src, j->n, j->dst, j->hist, t);
-                        j = eg.full() ? nullptr : pop(false, PlaneJob::kEncode);
+                        j = eg.full() ? nullptr : pop(false, kEnc);
                     }
-                    eg.step([](void* tag, size_t len) { Tag* t = static_cast<Tag*>(tag); finish(t->job, len, t->t0); t->job = nullptr; });
-                    if (!eg.full()) j = pop(false, PlaneJob::kEncode);
+                    eg.step(on_end);
+                    if (!eg.full()) j = pop(false, kEnc);
                 }
             }
         }
@@ -844,7 +1039,8 @@ private:
 
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<PlaneJob*> enc_q_, dec_q_;
+    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_;
+    const bool vec_ok_ = vec_available();
     std::vector<std::thread> workers_;
     bool stop_ = false;
     int dec_streams_ = kMaxDecStreams;

@@ -39,6 +39,10 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n);
 // produced[k] as decode_plane's return value, (size_t)-1 for a stream that is not decodable.
 void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced);
 
+// `count` dominant-symbol planes (any lengths) on the calling thread, up to 16 at a time in the AVX-512 loop
+// (wr_rangecoder_vec.h); false if the CPU lacks AVX-512.  Same symbols as decode_plane on each.
+bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced);
+
 // ---- process-wide coder pool: plane streams of ALL concurrent encode / decode calls are coded by a fixed set
 // of worker threads.  A worker interleaves up to 3 encoder or up to `dec_streams` (<= kMaxDecStreams) decoder
 // streams in one symbol loop, whichever fields they belong to; streams join at block boundaries as others

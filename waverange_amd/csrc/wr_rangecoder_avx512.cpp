@@ -1,0 +1,128 @@
+// wr_rangecoder_avx512.cpp -- see wr_rangecoder_vec.h.  Compiled with -mavx512f -mavx512bw -mavx512dq -mavx512vl;
+// entered only when vec_available().
+#include "wr_rangecoder_vec.h"
+
+#include <immintrin.h>
+#include <stdlib.h>
+
+namespace wrrc {
+
+namespace {
+
+constexpr uint32_t kTop = 0x80000000u;     // rangecod.c:121
+constexpr uint32_t kBottom = 0x00800000u;  // rangecod.c:129
+constexpr int kExtra = 7;                  // rangecod.c:128
+constexpr uint32_t kBlockSyms = 60000;     // defs.h:36
+
+// transpose of a 16 x 16 byte matrix held in 16 xmm registers (rows in, columns out)
+inline void transpose16x16(__m128i r[16])
+{
+    __m128i t[16];
+    for (int i = 0; i < 8; i++) { t[2 * i] = _mm_unpacklo_epi8(r[i], r[i + 8]); t[2 * i + 1] = _mm_unpackhi_epi8(r[i], r[i + 8]); }
+    for (int i = 0; i < 8; i++) { r[2 * i] = _mm_unpacklo_epi8(t[i], t[i + 8]); r[2 * i + 1] = _mm_unpackhi_epi8(t[i], t[i + 8]); }
+    for (int i = 0; i < 8; i++) { t[2 * i] = _mm_unpacklo_epi8(r[i], r[i + 8]); t[2 * i + 1] = _mm_unpackhi_epi8(r[i], r[i + 8]); }
+    for (int i = 0; i < 8; i++) { r[2 * i] = _mm_unpacklo_epi8(t[i], t[i + 8]); r[2 * i + 1] = _mm_unpackhi_epi8(t[i], t[i + 8]); }
+}
+
+}  // namespace
+
+bool vec_available()
+{
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
+                           !(getenv("WR_NO_AVX512") && atoi(getenv("WR_NO_AVX512")));
+    return ok;
+}
+
+void vec_decode_two_symbol_block(VecBlock* b, VecOther other)
+{
+    const __mmask16 act = (__mmask16)b->active;
+    const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
+    // inactive lanes idle on a state that never renormalises and always "hits" symbol 0
+    __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
+    __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
+    const __m512i lt0 = _mm512_maskz_loadu_epi32(act, b->lt[0]), lt1 = _mm512_maskz_loadu_epi32(act, b->lt[1]);
+    const __m512i sy0 = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[0]);
+    const __m512i sy1 = _mm512_maskz_loadu_epi32(act, b->sy[1]);
+    const __mmask16 top0 = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[0]), _mm512_setzero_si512());
+    const __mmask16 top1 = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[1]), _mm512_setzero_si512());
+    const __m512i sym0 = _mm512_maskz_loadu_epi32(act, b->sym[0]), sym1 = _mm512_maskz_loadu_epi32(act, b->sym[1]);
+    // floor(x / 60000) = ((x >> 5) * 146601551) >> 38 for every 32-bit x (checked exhaustively over x >> 5 < 2^27)
+    const __m512i magic = _mm512_set1_epi64(146601551);
+    const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
+
+    const uint8_t* p[kVecLanes];
+    uint8_t* d[kVecLanes];
+    alignas(64) uint32_t nb[kVecLanes];
+    for (int j = 0; j < kVecLanes; j++) {
+        p[j] = b->ptr[j]; d[j] = b->dst[j]; nb[j] = 0;
+        if (act >> j & 1) nb[j] = ((((uint32_t)p[j][-1] << 8) | p[j][0]) >> (8 - kExtra)) & 0xff;
+    }
+    // the byte every lane would shift in next: bits of the stream starting 7 bits into ptr[-1] (rangecod.c:297-299)
+    __m512i nextbits = _mm512_load_si512(nb);
+    alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
+    __m128i rows[16];
+
+    for (uint32_t i = 0; i < kBlockSyms; i++) {
+        // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in
+        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
+        while (sh) {
+            low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), nextbits);
+            range = _mm512_mask_slli_epi32(range, sh, range, 8);
+            unsigned m = sh;
+            do {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                const uint8_t* q = ++p[j];
+                const uint32_t v = ((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff;
+                nextbits = _mm512_mask_set1_epi32(nextbits, (__mmask16)(1u << j), (int)v);
+            } while (m);
+            sh = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256, rare
+        }
+        // ---- help = range / 60000 (rangecod.c:312)
+        const __m512i n5 = _mm512_srli_epi32(range, 5);
+        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
+        const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
+        const __m512i help = _mm512_or_si512(ev, od);
+        // ---- which of the two dominant symbols: low - help*lt < width of its interval (rangecod.c:313-319, 339-351)
+        const __m512i a0 = _mm512_mullo_epi32(help, lt0), a1 = _mm512_mullo_epi32(help, lt1);
+        const __m512i w0 = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy0), top0, range, a0);
+        const __m512i w1 = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy1), top1, range, a1);
+        const __mmask16 in0 = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a0), w0);
+        const __mmask16 in1 = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a1), w1);
+        __m512i c = _mm512_mask_blend_epi32(in0, sym1, sym0);
+        __m512i nlow = _mm512_sub_epi32(low, _mm512_mask_blend_epi32(in0, a1, a0));
+        __m512i nrange = _mm512_mask_blend_epi32(in0, w1, w0);
+        const __mmask16 miss = act & ~(in0 | in1);
+        if (__builtin_expect(miss != 0, 0)) {  // some other symbol: scalar look-up path for those lanes
+            _mm512_store_si512(tl, low); _mm512_store_si512(tr, range); _mm512_store_si512(th, help);
+            unsigned m = miss;
+            do {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t cj = other(b->model[j], &tl[j], &tr[j], th[j]);
+                const __mmask16 one = (__mmask16)(1u << j);
+                nlow = _mm512_mask_set1_epi32(nlow, one, (int)tl[j]);
+                nrange = _mm512_mask_set1_epi32(nrange, one, (int)tr[j]);
+                c = _mm512_mask_set1_epi32(c, one, (int)cj);
+            } while (m);
+        }
+        low = nlow; range = nrange;
+        // ---- symbols out: 16 steps are collected and transposed into 16 bytes per lane
+        rows[i & 15] = _mm512_cvtepi32_epi8(c);
+        if ((i & 15) == 15) {
+            transpose16x16(rows);
+            unsigned m = act;
+            while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                _mm_storeu_si128(reinterpret_cast<__m128i*>(d[j] + (i - 15)), rows[j]);
+            }
+        }
+    }
+    _mm512_mask_storeu_epi32(b->low, act, low);
+    _mm512_mask_storeu_epi32(b->range, act, range);
+    for (int j = 0; j < kVecLanes; j++) b->ptr[j] = p[j];
+}
+
+}  // namespace wrrc
