@@ -464,6 +464,10 @@ struct BlockModel {
     // bucket table: symbol of all 16 values [16 j, 16 j + 15] if they agree, else kMixed.  15 KB for four
     // planes stays in L1, the four 60 KB lookup tables do not.  Used when < 2 % of the block
     // falls into mixed buckets (each escape is a branch miss).
+    // the four most probable symbols for the 16-lane vector loop (unused entries: sy 0), and whether they hold
+    // >= WR_RC_MPS_PCT of the block
+    uint32_t cand[4], cand_lt[4], cand_sy[4];
+    bool cand_ok;
     bool use_buckets;
     bool tables_ready;  // bucket / lookup are filled in (the vector loop builds them only when a rare symbol turns up)
     uint16_t bucket[kBuckets];
@@ -517,6 +521,21 @@ void finish_model_stats(BlockModel& m)
     m.few = (!m.mps_on && distinct >= 3 && distinct <= 4) ? distinct : 0;
     for (uint32_t j = distinct; j < 4; j++) { m.few_sym[j] = m.top; m.few_lt[j] = 0xffff; m.few_sy[j] = 0; }  // help * 0xffff > low, always
     if (m.few) m.mps_on = true;
+    // candidates of the vector loop
+    uint32_t covered = 0;
+    for (int e = 0; e < 4; e++) {
+        int best = -1;
+        for (int b = 0; b < 256; b++) {
+            if (!m.tab[b].sy || (best >= 0 && m.tab[b].sy <= m.tab[best].sy)) continue;
+            bool used = false;
+            for (int f = 0; f < e; f++) used = used || (m.cand_sy[f] && m.cand[f] == (uint32_t)b);
+            if (!used) best = b;
+        }
+        if (best < 0) { m.cand[e] = 0; m.cand_lt[e] = 0; m.cand_sy[e] = 0; continue; }
+        m.cand[e] = (uint32_t)best; m.cand_lt[e] = m.tab[best].lt; m.cand_sy[e] = m.tab[best].sy;
+        covered += m.tab[best].sy;
+    }
+    m.cand_ok = m.bs && (uint64_t)covered * 100 >= (uint64_t)m.bs * WR_RC_MPS_PCT;
 }
 
 void finish_model(BlockModel& m)
@@ -748,7 +767,7 @@ uint32_t vec_other_symbol(const void* model, uint32_t* low, uint32_t* range, uin
     return c;
 }
 
-// Up to 16 plane streams whose blocks mostly hold two dominant symbols, advancing block by block in lockstep on
+// Up to 16 plane streams whose blocks are mostly held by at most four symbols, advancing block by block in lockstep on
 // one thread: the blocks of that kind are decoded 16 lanes at a time by the AVX-512 loop, the occasional other
 // block by the scalar loop of its stream.
 class VecDecGroup {
@@ -795,7 +814,7 @@ public:
                 d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
             }
             const bool fast = m.bs == kBlock && produced_[k] + kBlock <= n_[k] && d.pos + kMargin <= d.len;
-            vec[k] = fast && m.mps_on && !m.few;
+            vec[k] = fast && m.cand_ok;
             k++;
         }
         if (!count_) return;
@@ -807,14 +826,16 @@ public:
             const BlockModel& m = *ms_[k];
             vb.active |= 1u << k;
             vb.low[k] = d.low; vb.range[k] = d.range; vb.ptr[k] = d.in + d.pos; vb.dst[k] = dst_[k];
-            for (int e = 0; e < 2; e++) {
-                vb.lt[e][k] = m.mps_lt[e]; vb.sy[e][k] = m.mps_sy[e]; vb.is_top[e][k] = m.mps_is_top[e]; vb.sym[e][k] = m.mps[e];
+            for (int e = 0; e < kVecCand; e++) {
+                vb.lt[e][k] = m.cand_lt[e]; vb.sy[e][k] = m.cand_sy[e]; vb.sym[e][k] = m.cand[e];
+                vb.is_top[e][k] = m.cand_sy[e] && m.cand[e] == m.top;
             }
             vb.model[k] = &m;
         }
         if (vb.active) {
-            for (int k = 0; k < kCap; k++) if (!(vb.active >> k & 1)) { vb.is_top[0][k] = vb.is_top[1][k] = 0; vb.ptr[k] = nullptr; vb.dst[k] = nullptr; }
-            vec_decode_two_symbol_block(&vb, vec_other_symbol);
+            for (int k = 0; k < kCap; k++)
+                if (!(vb.active >> k & 1)) { for (int e = 0; e < kVecCand; e++) vb.is_top[e][k] = 0; vb.ptr[k] = nullptr; vb.dst[k] = nullptr; }
+            vec_decode_block(&vb, vec_other_symbol);
             for (int k = 0; k < count_; k++) {
                 if (!vec[k]) continue;
                 Dec& d = *ds_[k];

@@ -34,19 +34,21 @@ bool vec_available()
     return ok;
 }
 
-void vec_decode_two_symbol_block(VecBlock* b, VecOther other)
+void vec_decode_block(VecBlock* b, VecOther other)
 {
     const __mmask16 act = (__mmask16)b->active;
     const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
-    // inactive lanes idle on a state that never renormalises and always "hits" symbol 0
+    // inactive lanes idle on a state that never renormalises and always "hits" candidate 0
     __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
     __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
-    const __m512i lt0 = _mm512_maskz_loadu_epi32(act, b->lt[0]), lt1 = _mm512_maskz_loadu_epi32(act, b->lt[1]);
-    const __m512i sy0 = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[0]);
-    const __m512i sy1 = _mm512_maskz_loadu_epi32(act, b->sy[1]);
-    const __mmask16 top0 = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[0]), _mm512_setzero_si512());
-    const __mmask16 top1 = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[1]), _mm512_setzero_si512());
-    const __m512i sym0 = _mm512_maskz_loadu_epi32(act, b->sym[0]), sym1 = _mm512_maskz_loadu_epi32(act, b->sym[1]);
+    __m512i lt[kVecCand], sy[kVecCand], sym[kVecCand];
+    __mmask16 top[kVecCand];
+    for (int e = 0; e < kVecCand; e++) {
+        lt[e] = _mm512_maskz_loadu_epi32(act, b->lt[e]);
+        sy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
+        sym[e] = _mm512_maskz_loadu_epi32(act, b->sym[e]);
+        top[e] = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[e]), _mm512_setzero_si512());
+    }
     // floor(x / 60000) = ((x >> 5) * 146601551) >> 38 for every 32-bit x (checked exhaustively over x >> 5 < 2^27)
     const __m512i magic = _mm512_set1_epi64(146601551);
     const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
@@ -84,15 +86,23 @@ void vec_decode_two_symbol_block(VecBlock* b, VecOther other)
         const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
         const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
         const __m512i help = _mm512_or_si512(ev, od);
-        // ---- which of the two dominant symbols: low - help*lt < width of its interval (rangecod.c:313-319, 339-351)
-        const __m512i a0 = _mm512_mullo_epi32(help, lt0), a1 = _mm512_mullo_epi32(help, lt1);
-        const __m512i w0 = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy0), top0, range, a0);
-        const __m512i w1 = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy1), top1, range, a1);
-        const __mmask16 in0 = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a0), w0);
-        const __mmask16 in1 = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a1), w1);
-        __m512i c = _mm512_mask_blend_epi32(in0, sym1, sym0);
-        __m512i nlow = _mm512_sub_epi32(low, _mm512_mask_blend_epi32(in0, a1, a0));
-        __m512i nrange = _mm512_mask_blend_epi32(in0, w1, w0);
+        // ---- which candidate: low - help*lt < width of its interval (rangecod.c:313-319, 339-351).  The intervals
+        // are disjoint, so at most one test holds; an unused entry has width 0.
+        __m512i a[kVecCand], w[kVecCand];
+        __mmask16 in[kVecCand];
+        for (int e = 0; e < kVecCand; e++) {
+            a[e] = _mm512_mullo_epi32(help, lt[e]);
+            w[e] = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy[e]), top[e], range, a[e]);
+            in[e] = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a[e]), w[e]);
+        }
+        __m512i c = sym[0], sa = a[0], nrange = w[0];
+        for (int e = 1; e < kVecCand; e++) {
+            c = _mm512_mask_mov_epi32(c, in[e], sym[e]);
+            sa = _mm512_mask_mov_epi32(sa, in[e], a[e]);
+            nrange = _mm512_mask_mov_epi32(nrange, in[e], w[e]);
+        }
+        __m512i nlow = _mm512_sub_epi32(low, sa);
+        const __mmask16 in0 = in[0], in1 = (__mmask16)(in[1] | in[2] | in[3]);
         const __mmask16 miss = act & ~(in0 | in1);
         if (__builtin_expect(miss != 0, 0)) {  // some other symbol: scalar look-up path for those lanes
             _mm512_store_si512(tl, low); _mm512_store_si512(tr, range); _mm512_store_si512(th, help);
