@@ -11,6 +11,7 @@
 #include "wr_rangecoder.h"
 #include "wr_rangecoder_vec.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -986,7 +987,13 @@ private:
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            if ((want == kAny || want == kVec) && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); if (got) *got = kVec; return j; }
+            // vector-decode jobs are only worth it many lanes at a time: at most vec_sessions_max_ workers run a
+            // vector session; what is queued beyond that waits for one of them to have a lane free (they top up
+            // at every block boundary, a fraction of a millisecond)
+            if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
+            if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max_) {
+                PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
+            }
             if ((want == kAny || want == kDec) && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); if (got) *got = kDec; return j; }
             if ((want == kAny || want == kEnc) && !enc_q_.empty()) { PlaneJob* j = enc_q_.front(); enc_q_.pop_front(); if (got) *got = kEnc; return j; }
             if (!block || stop_) return nullptr;
@@ -1031,6 +1038,8 @@ private:
                     vg->step(on_end);
                     if (!vg->full()) j = pop(false, kVec);
                 }
+                { std::lock_guard<std::mutex> lk(mu_); vec_sessions_--; }
+                cv_.notify_all();  // vector jobs queued meanwhile may start a session of their own now
             } else if (kind == kDec) {
                 if (!dg) dg.reset(new DecGroup(dec_streams));
                 while (j || dg->count()) {
@@ -1062,6 +1071,8 @@ private:
     std::condition_variable cv_;
     std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_;
     const bool vec_ok_ = vec_available();
+    int vec_sessions_ = 0;
+    const int vec_sessions_max_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 2;
     std::vector<std::thread> workers_;
     bool stop_ = false;
     int dec_streams_ = kMaxDecStreams;
