@@ -987,9 +987,11 @@ private:
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            // vector-decode jobs are only worth it many lanes at a time: at most vec_sessions_max_ workers run a
-            // vector session; what is queued beyond that waits for one of them to have a lane free (they top up
-            // at every block boundary, a fraction of a millisecond)
+            // at most vec_sessions_max_ workers run a vector session at a time (WR_VEC_SESSIONS; default: no limit
+            // that matters -- two sessions for all planes were measured: fewer CPUs busy, but every stream then
+            // advances at 1/16 of a loop that is latency-bound at ~75 cycles per step, and the fields in flight
+            // wait longer for their planes); what is queued beyond that joins a running session at its next
+            // block boundary
             if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
             if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max_) {
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
@@ -1072,7 +1074,7 @@ private:
     std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_;
     const bool vec_ok_ = vec_available();
     int vec_sessions_ = 0;
-    const int vec_sessions_max_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 2;
+    const int vec_sessions_max_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 64;
     std::vector<std::thread> workers_;
     bool stop_ = false;
     int dec_streams_ = kMaxDecStreams;
