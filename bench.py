@@ -478,6 +478,9 @@ def main():
             api.set_threads(args.threads, args.enc_threads)
             ncores = max(1, int(limits["cpus_per_rank"]))
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols, ncores)
+            # GPU path over the CPU reference on this box (vs_baseline stays null: BASELINE.md has no published number)
+            out["vs_cpu_baseline"] = {"one_core": round(out["value"] / out["cpu_baseline"]["value"], 1),
+                                      "all_cores": round(out["value"] / out["cpu_baseline"]["all_cores"]["value"], 2)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -282,3 +282,42 @@ def test_config4_sharded_fields_container_vs_oracle(oracle, tmp_path):
         return h.hexdigest()
 
     assert file_sha(tmp_path / "data.wrb") == file_sha(tmp_path / "want.wrb")
+
+
+def test_coder_pool_codes_all_fields_in_flight(api, oracle):
+    """wr_set_coder_pool: the planes of all concurrent encode / decode calls go to a fixed set of worker threads that
+    interleave streams of different fields (and send dominant-symbol planes through the 16-lane AVX-512 loop where
+    the CPU has it).  Streams, header scalars and reconstructions must not change."""
+    jobs = [((96, 96, 96), 1e-7, 1), ((128, 64, 80), 1e-3, 2), ((180, 190, 200), 1e-7, 3), ((64, 64, 64), 1e-16, 4),
+            ((200, 120, 72), 1e-5, 5), ((37, 21, 13), 1e-6, 6)]
+    want = {}
+    for shape, tol, seed in jobs:
+        f = synth.field(*shape, seed=seed)
+        e = oracle.encode(f, tol)
+        want[(shape, tol, seed)] = (f, e, oracle.decode(e, f.shape))
+    api.set_coder_pool(4)
+    errors = []
+
+    def worker(job):
+        try:
+            f, e, rec = want[job]
+            with api.Context(0) as c:
+                for _ in range(3):
+                    enc, _ = c.encode_host(f, job[1])
+                    same_as_oracle(enc, e)
+                    enc["data"] = enc["data"].copy()
+                    out = np.empty_like(f)
+                    c.decode_host(out, enc)
+                    assert bits_equal(out, rec)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((job, exc))
+
+    try:
+        ths = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        api.set_coder_pool(0)
+    assert not errors, errors
