@@ -153,7 +153,8 @@ struct wr_ctx {
     double* d_mm = nullptr; size_t mm_records = 0;  // min/max records of the fused forward transform
     unsigned long long* d_idx = nullptr;
     // pinned host
-    double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index
+    double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index, [4..7] fused min/max
+    double* h_result_dev = nullptr;  // the same block as the device sees it: reductions write their result straight to the host
     uint8_t* h_plane[WR_NLAYMAX] = {nullptr}; size_t h_plane_bytes[WR_NLAYMAX] = {0};  // pinned, one per plane, on demand
     bool h_plane_pinned[WR_NLAYMAX] = {false};
     uint16_t* h_hist = nullptr; size_t h_hist_elems = 0;  // pinned: per-block byte histograms, all planes
@@ -434,8 +435,8 @@ int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int n
 // delay the answer.
 int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn, double* mx)
 {
-    if (!pending) wrk::minmax(d_x, n, c->d_partial, c->d_result, c->stream);
-    HIPCHK(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // the final reduction kernel stores min and max straight into pinned host memory: no copy command
+    if (!pending) wrk::minmax(d_x, n, c->d_partial, c->h_result_dev, c->stream);
     HIPCHK(hipEventRecord(c->ev_mm, c->stream));
     HIPCHK(hipEventSynchronize(c->ev_mm));
     double lo = c->h_result[0], hi = c->h_result[1];
@@ -579,6 +580,7 @@ static int ctx_init(wr_ctx* c, int device, void* hip_stream)
     HIPCHK(hipMalloc(&c->d_result, 4 * sizeof(double)));
     HIPCHK(hipMalloc(&c->d_idx, sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->h_result, 8 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_result_dev), c->h_result, 0));
     for (int i = 0; i < WR_NLAYMAX; i++) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_plane[i], hipEventDisableTiming));
     }
@@ -694,6 +696,13 @@ int wr_host_free(void* ptr)
 int wr_dev_upload(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));  // ordered behind what the context has queued, like a stream copy
+    if (bytes >= (1u << 20) && c->x_field.sig && wrdma::can_copy(dst, src)) {  // pinned host memory: SDMA engine
+        std::lock_guard<std::mutex> lk(c->mu);
+        wrdma::signal_arm(c->x_field.sig, 1);
+        if (wrdma::copy_async(dst, src, bytes, c->x_field.sig) != 0) { wrdma::signal_cancel(c->x_field.sig, 1); return fail(WR_ERR_HIP, "DMA copy could not be queued"); }
+        return wrdma::wait(c->x_field.sig) == 0 ? WR_OK : fail(WR_ERR_HIP, "DMA copy failed");
+    }
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return WR_OK;
@@ -702,6 +711,13 @@ int wr_dev_upload(wr_ctx* c, void* dst, const void* src, size_t bytes)
 int wr_dev_download(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bytes >= (1u << 20) && c->x_field.sig && wrdma::can_copy(dst, src)) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        wrdma::signal_arm(c->x_field.sig, 1);
+        if (wrdma::copy_async(dst, src, bytes, c->x_field.sig) != 0) { wrdma::signal_cancel(c->x_field.sig, 1); return fail(WR_ERR_HIP, "DMA copy could not be queued"); }
+        return wrdma::wait(c->x_field.sig) == 0 ? WR_OK : fail(WR_ERR_HIP, "DMA copy failed");
+    }
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return WR_OK;
@@ -720,8 +736,7 @@ int wr_dev_linf(wr_ctx* c, const double* d_a, const double* d_b, size_t n, doubl
 {
     if (int rc = ctx_bind(c)) return rc;
     if (!n) return fail(WR_ERR_ARG, "empty array");
-    wrk::linf_diff(d_a, d_b, n, c->d_partial, c->d_result, c->stream);
-    HIPCHK(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    wrk::linf_diff(d_a, d_b, n, c->d_partial, c->h_result_dev, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     *max_abs_diff = c->h_result[0];
     *max_abs_a = c->h_result[1];
@@ -760,7 +775,7 @@ int wr_dev_quantize_plane(wr_ctx* c, double* d_x, size_t n, double deps, double 
     if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 1)) return fail(WR_ERR_ARG, "misaligned device pointer");
     const double aopt = 1.0 / deps;
     const double bopt = -minval * aopt + 0.5;
-    wrk::quantize_plane(d_x, n, aopt, bopt, deps, minval, d_q, true, c->d_partial, c->d_result, c->stream);
+    wrk::quantize_plane(d_x, n, aopt, bopt, deps, minval, d_q, true, c->d_partial, c->h_result_dev, c->stream);
     HIPCHK(hipGetLastError());
     return read_minmax(c, d_x, n, true, next_min, next_max);
 }
@@ -844,9 +859,8 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         info->wlev = kWavLvl;
         double* const d_in = d_fld;
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
-        wrk::transform_fwd_fused(d_in, slot->scratch, slot->lowbuf, nx, ny, nz, c->stream, c->d_mm, c->d_result);
+        wrk::transform_fwd_fused(d_in, slot->scratch, slot->lowbuf, nx, ny, nz, c->stream, c->d_mm, c->h_result_dev + 4);
         HIPCHK(hipEventRecord(c->ev_c, c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_result + 4, c->d_result, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(c->ev_mm, c->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventSynchronize(c->ev_mm));
@@ -912,15 +926,14 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
             lc.tolabs = info->tolabs;
             lc.span = hi - lo;
             wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, lc,
-                                      c->d_partial, c->d_result, c->stream);
+                                      c->d_partial, c->h_result_dev, c->stream);
         } else
         wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, resid_upd,
-                            c->d_partial, c->d_result, c->stream);
+                            c->d_partial, c->h_result_dev, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
         HIPCHK(hipGetLastError());
-        // the next plane's min/max goes to the host first; what after_quant enqueues runs behind it
-        if (!s.last)
-            HIPCHK(hipMemcpyAsync(c->h_result, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // the next plane's min/max is in host memory when this event fires (the reduction stores it there); what
+        // after_quant enqueues runs behind it
         HIPCHK(hipEventRecord(c->ev_mm, c->stream));
         if (int rc = after_quant(ilay)) return rc;
         HIPCHK(hipEventRecord(c->ev_plane[ilay], c->stream));
