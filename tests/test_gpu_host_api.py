@@ -283,6 +283,27 @@ def test_config4_sharded_fields_container_vs_oracle(oracle, tmp_path):
 
     assert file_sha(tmp_path / "data.wrb") == file_sha(tmp_path / "want.wrb")
 
+    # and back through the launcher's decoder mode (wrdec's five arguments): every rank writes its fields at their
+    # offsets of one output file, which must hold the oracle's reconstructions bit for bit
+    recs = [None] * nf
+
+    def cpu_dec(i):
+        recs[i] = oracle.decode(encs[i], fields[i].shape)
+
+    ths = [threading.Thread(target=cpu_dec, args=(i,)) for i in range(nf)]
+    for t in ths:
+        t.start()
+    cmd = cmd[:cmd.index("waverange_amd.sharded") + 1] + [str(tmp_path / "data.wrb"), str(tmp_path / "data.wrh"), str(tmp_path / "datarec.bin"), "2", "0"]
+    cmd[cmd.index("29533")] = "29534"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path))
+    for t in ths:
+        t.join()
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = np.memmap(tmp_path / "datarec.bin", dtype=np.float64, mode="r")
+    assert got.size == nf * n ** 3
+    for i in range(nf):
+        assert bits_equal(got[i * n ** 3:(i + 1) * n ** 3], recs[i]), i
+
 
 def test_coder_pool_codes_all_fields_in_flight(api, oracle):
     """wr_set_coder_pool: the planes of all concurrent encode / decode calls go to a fixed set of worker threads that

@@ -34,6 +34,9 @@ for fd in c["fields"]:
 codec = lambda fld, tol: o.encode(fld, tol)
 sharded.wrenc_sharded(os.path.join(workdir, "data.bin"), os.path.join(workdir, "data.wrb"),
                       os.path.join(workdir, "data.wrh"), specs, c["file_type"], bool(c["flip"]), codec, dist)
+# and back: every rank decodes its fields and writes them at their offsets of the output file
+sharded.wrdec_sharded(os.path.join(workdir, "data.wrb"), os.path.join(workdir, "data.wrh"), os.path.join(workdir, "datarec.bin"),
+                      c["file_type"], bool(c["flip"]), lambda enc, shape: o.decode(enc, shape), dist)
 print("rank", dist.get_rank(), "fields", sharded.plan(len(specs), dist.get_world_size())[dist.get_rank()])
 dist.destroy_process_group()
 '''
@@ -62,6 +65,8 @@ def test_sharded_wrenc_world2_gloo(case):
         assert r.returncode == 0, r.stderr[-2000:]
         assert open(os.path.join(d, "data.wrh")).read() == g["wrh"]
         assert hashlib.sha256(open(os.path.join(d, "data.wrb"), "rb").read()).hexdigest() == g["wrb_sha256"]
+        assert os.path.getsize(os.path.join(d, "datarec.bin")) == g["rec_size"]
+        assert hashlib.sha256(open(os.path.join(d, "datarec.bin"), "rb").read()).hexdigest() == g["rec_sha256"], "decoded file differs"
 
 
 def test_single_process_matches_too():
@@ -82,3 +87,6 @@ def test_single_process_matches_too():
                               specs, c["file_type"], bool(c["flip"]), lambda f, t: o.encode(f, t))
         assert open(os.path.join(d, "data.wrh")).read() == g["wrh"]
         assert hashlib.sha256(open(os.path.join(d, "data.wrb"), "rb").read()).hexdigest() == g["wrb_sha256"]
+        sharded.wrdec_sharded(os.path.join(d, "data.wrb"), os.path.join(d, "data.wrh"), os.path.join(d, "datarec.bin"),
+                              c["file_type"], bool(c["flip"]), lambda enc, shape: o.decode(enc, shape))
+        assert hashlib.sha256(open(os.path.join(d, "datarec.bin"), "rb").read()).hexdigest() == g["rec_sha256"]

@@ -134,6 +134,77 @@ def wrenc_sharded(in_path, wrb_path, wrh_path, specs, file_type, flip, codec, di
         dist.barrier()
 
 
+def read_container_header(wrh_path):
+    """Parse a `.wrh` file (reference gen_dec.cpp:160-168, gen_aux.cpp:559-644) into (nf, [field dicts])."""
+    with open(wrh_path) as fh:
+        lines = fh.read().split("\n")
+    nf = int(lines[5].split(":")[-1])
+    pos = 6
+    fields = []
+    for i in range(nf):
+        assert lines[pos].strip() == "-----" and int(lines[pos + 1]) == i, "encoding header file read error"
+        f = dict(nbytes=int(lines[pos + 3]), recl=bytes(int(t, 16) for t in lines[pos + 4].split()))
+        f["nx"], f["ny"], f["nz"], f["nh"], f["idinv"], f["icomp"] = (int(lines[pos + 5 + k]) for k in range(6))
+        pos += 11
+        if f["icomp"]:
+            f["tol_base"], f["tolabs"], f["midval"], f["halfspanval"] = (float(lines[pos + k]) for k in range(4))
+            f["wlev"], f["nlay"], f["ntot_enc"] = (int(lines[pos + 4 + k]) for k in range(3))
+            pos += 7
+            if f["ntot_enc"] > 0:
+                f["deps_vec"] = np.array([float(t) for t in lines[pos].split()])
+                f["minval_vec"] = np.array([float(t) for t in lines[pos + 1].split()])
+                f["len_enc_vec"] = [int(t) for t in lines[pos + 2].split()]
+                pos += 3
+        fields.append(f)
+    return nf, fields
+
+
+def wrdec_sharded(wrb_path, wrh_path, out_path, file_type, flip, decoder, dist=None):
+    """Sharded generic decoder: every rank decodes its fields (round robin) and writes them at their byte
+    offsets of the output file, which has the layout of the original input (reference gen_aux.cpp:49-226:
+    record markers from the header, fp32 / fp64, endian flip, inverted dimension order).
+    decoder(enc dict incl. data, shape (nz*nh, ny, nx)) -> float64 array."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    nf, fields = read_container_header(wrh_path)
+    ml = 4 if file_type == 0 else (8 if file_type == 1 else 0)
+    src, dst, a, b = [], [], 0, 0
+    for f in fields:
+        n = f["nx"] * f["ny"] * f["nz"] * f["nh"]
+        src.append(a)
+        dst.append(b)
+        a += f["ntot_enc"] if f["icomp"] else f["nbytes"] * n
+        b += 2 * ml + f["nbytes"] * n
+    if rank == 0:
+        with open(out_path, "wb") as fh:
+            fh.truncate(b)
+    if dist is not None and world > 1:
+        dist.barrier()
+    with open(wrb_path, "rb") as fin, open(out_path, "r+b") as fout:
+        for i in plan(nf, world)[rank]:
+            f = fields[i]
+            shape = (f["nz"] * f["nh"], f["ny"], f["nx"])
+            n = shape[0] * shape[1] * shape[2]
+            fin.seek(src[i])
+            if not f["icomp"]:
+                fld = np.frombuffer(fin.read(f["nbytes"] * n), dtype="<f4" if f["nbytes"] == 4 else "<f8").astype(np.float64)
+            elif f["ntot_enc"] == 0:
+                fld = np.full(n, f["midval"])  # gen_dec.cpp:201
+            else:
+                enc = {k: f[k] for k in ("tolabs", "midval", "halfspanval", "wlev", "nlay", "ntot_enc", "deps_vec", "minval_vec", "len_enc_vec")}
+                enc["data"] = np.frombuffer(fin.read(f["ntot_enc"]), dtype=np.uint8)
+                fld = np.asarray(decoder(enc, shape), dtype=np.float64)
+            arr = fld.reshape(f["nh"], f["nz"], f["ny"], f["nx"])
+            if f["idinv"]:
+                arr = arr.transpose(3, 2, 1, 0)
+            dt = np.dtype("f4" if f["nbytes"] == 4 else "f8").newbyteorder(">" if flip else "<")
+            marker = f["recl"][:ml][::-1] if flip else f["recl"][:ml]
+            fout.seek(dst[i])
+            fout.write(marker + np.ascontiguousarray(arr).astype(dt).tobytes() + marker)
+    if dist is not None and world > 1:
+        dist.barrier()
+
+
 def gpu_codec(device):
     """The product codec for wrenc_sharded: wr_encode_host on this rank's GPU (field and coded bytes in host
     memory, exactly what the drop-in encoding_wrap runs)."""
@@ -149,28 +220,63 @@ def gpu_codec(device):
     return codec
 
 
+def gpu_decoder(device):
+    """The product decoder for wrdec_sharded: wr_decode_host on this rank's GPU."""
+    from . import api
+    ctx = api.Context(device)
+
+    def decoder(enc, shape):
+        out = np.empty(shape, dtype=np.float64)
+        ctx.decode_host(out, enc)
+        return out
+
+    decoder.close = ctx.close
+    return decoder
+
+
 def main(argv=None):
-    """Sharded generic encoder, one process per GPU:
+    """Sharded generic encoder / decoder, one process per GPU:
 
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
             -m waverange_amd.sharded IN OUT HDR TYPE ENDIANFLIP NF PRECISION NX NY NZ TOL
 
-    (the generic wrenc command line, reference src/generic/gen_enc.cpp:365-412; every field has the same
-    shape and tolerance in this mode).  Rank r codes fields r, r + N, ... on GPU LOCAL_RANK (modulo the
-    visible GPUs); rank 0 gathers the coded fields over gloo -- host bytes, no GPU tensors travel -- and
-    writes the .wrh / .wrb pair in field order.  Without a launcher it runs as a single process."""
+            -m waverange_amd.sharded ENC HDR OUT TYPE ENDIANFLIP
+
+    (the generic wrenc / wrdec command lines, reference src/generic/gen_enc.cpp:365-412, gen_dec.cpp:105-117;
+    every field has the same shape and tolerance in the encoder's argument mode).  Rank r codes fields r, r + N,
+    ... on GPU LOCAL_RANK (modulo the visible GPUs).  Encoder: rank 0 gathers the coded fields over gloo -- host
+    bytes, no GPU tensors travel -- and writes the .wrh / .wrb pair in field order.  Decoder: every rank writes
+    its fields at their offsets of the output file.  Without a launcher it runs as a single process."""
     import os
     import sys
     argv = list(sys.argv[1:] if argv is None else argv)
-    if len(argv) != 11:
+    if len(argv) not in (5, 11):
         sys.stderr.write(main.__doc__ + "\n")
         return 2
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if len(argv) == 5:
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        from . import api
+        api.set_verbosity(0)
+        ndev = api.device_count()
+        if ndev < 1:
+            raise SystemExit("waverange_amd.sharded: no GPU visible (libwaverange_amd has no CPU fallback)")
+        decoder = gpu_decoder(local_rank % ndev)
+        try:
+            wrdec_sharded(argv[0], argv[1], argv[2], int(argv[3]), bool(int(argv[4])), decoder, dist)
+        finally:
+            decoder.close()
+            if dist is not None:
+                dist.destroy_process_group()
+        return 0
     in_path, wrb_path, wrh_path = argv[0], argv[1], argv[2]
     file_type, flip, nf, prec = int(argv[3]), int(argv[4]), int(argv[5]), int(argv[6])
     nx, ny, nz, tol = int(argv[7]), int(argv[8]), int(argv[9]), float(argv[10])
     specs = [dict(nbytes=4 if prec == 1 else 8, nx=nx, ny=ny, nz=nz, nh=1, idinv=0, icomp=1, tol_base=tol) for _ in range(nf)]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
