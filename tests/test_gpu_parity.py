@@ -293,7 +293,8 @@ def test_local_cutoff_branch(ctx, oracle, shape, m):
 
 
 def test_full_size_1024_fused_vs_general_and_roundtrip(ctx, api):
-    """BASELINE full size (1024^3 fp64, 8 GiB).  No CPU oracle at this size, so:
+    """BASELINE full size (1024^3 fp64, 8 GiB): the two device implementations against each other (the coded
+    bytes against the oracle at this size: test_gpu_host_api.py::test_full_size_1024_coded_bytes_vs_oracle).
     (1) the fused single-pass kernels and the general 3-pass kernels -- two independent device
         implementations, each pinned to the oracle at small sizes -- must agree bit for bit,
         forward and inverse (compared on the device, max|a-b| == 0);
@@ -333,9 +334,9 @@ def test_full_size_1024_fused_vs_general_and_roundtrip(ctx, api):
     diff, amax = ctx.linf(b, a, n ** 3)
     # The reference's own error control is approximate (1.013e-3 at 256^3 for tol
     # 1e-3; WAV_ACC_COEF = 1.75 is an empirical allowance for the 4-level synthesis gain).  At
-    # 1024^3 the same arithmetic gives 1.09e-3; 512^3 is compared with the oracle bit for bit in
-    # test_large_roundtrip_properties, so this only guards the order of magnitude.
-    assert diff / amax < 1.25e-3
+    # 1024^3 the same arithmetic gives 1.09e-3 -- the reference's own figure: the coded bytes at this
+    # size equal the oracle's (tests/test_gpu_host_api.py::test_full_size_1024_coded_bytes_vs_oracle).
+    assert diff / amax < 1.1e-3
     a.free()
     b.free()
 

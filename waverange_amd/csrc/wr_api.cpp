@@ -149,7 +149,7 @@ struct wr_ctx {
     bool own_stream = false;
     bool keep_residual = false;
     double* d_cutoff = nullptr; size_t cutoff_elems = 0;  // local cutoff vector (mx*my*mz > 1 only)
-    double* d_partial = nullptr; double* d_result = nullptr;
+    double* d_partial = nullptr;
     double* d_mm = nullptr; size_t mm_records = 0;  // min/max records of the fused forward transform
     unsigned long long* d_idx = nullptr;
     // pinned host
@@ -430,7 +430,7 @@ int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int n
 // min/max of a device array with the reference's scan semantics (wrappers.cpp:244-250):
 // values from the reduction; if the minimum is a zero, its sign is that of the LAST zero in
 // memory order (glibc fmin keeps the later of equal operands -- oracle/wr_oracle.c:wro_minmax).
-// `pending` = the reduction has already been enqueued into d_result by a fused kernel.
+// `pending` = a fused kernel has already been enqueued that stores the reduction into h_result[0..1].
 // Waits on an event recorded right behind the read-back, so kernels enqueued afterwards do not
 // delay the answer.
 int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn, double* mx)
@@ -577,7 +577,6 @@ static int ctx_init(wr_ctx* c, int device, void* hip_stream)
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIPCHK(hipMalloc(&c->d_partial, 2 * wrk::minmax_partials() * sizeof(double)));
-    HIPCHK(hipMalloc(&c->d_result, 4 * sizeof(double)));
     HIPCHK(hipMalloc(&c->d_idx, sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->h_result, 8 * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_result_dev), c->h_result, 0));
@@ -627,7 +626,7 @@ void wr_ctx_destroy(wr_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cutoff);
-    (void)hipFree(c->d_partial); (void)hipFree(c->d_result); (void)hipFree(c->d_idx); (void)hipFree(c->d_mm);
+    (void)hipFree(c->d_partial); (void)hipFree(c->d_idx); (void)hipFree(c->d_mm);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_hist) (void)hipHostFree(c->h_hist);
     for (int l = 0; l < WR_NLAYMAX; l++) {

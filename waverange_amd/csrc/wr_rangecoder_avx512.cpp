@@ -53,15 +53,26 @@ void vec_decode_block(VecBlock* b, VecOther other)
     const __m512i magic = _mm512_set1_epi64(146601551);
     const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
 
-    const uint8_t* p[kVecLanes];
+    // Byte feed.  The stream enters `low` as a bit string that starts 7 bits into the byte held back
+    // (rangecod.c:297-299): the byte a lane shifts in at pointer q is ((q[-1] << 8 | q[0]) >> 1) & 0xff.  Every lane
+    // keeps a window of the next four such bytes (top byte first) and the count of those still unused; a lane
+    // whose window runs empty reloads it from its stream, four bytes ahead -- a scalar step per lane, but only
+    // every fourth byte it consumes.
+    const uint8_t* pw[kVecLanes];  // stream position the lane's window was loaded at
     uint8_t* d[kVecLanes];
-    alignas(64) uint32_t nb[kVecLanes];
+    alignas(64) uint32_t w0[kVecLanes];
+    auto window_at = [](const uint8_t* q) -> uint32_t {
+        uint64_t v;
+        __builtin_memcpy(&v, q - 1, 8);
+        return (uint32_t)(__builtin_bswap64(v) >> 25);
+    };
     for (int j = 0; j < kVecLanes; j++) {
-        p[j] = b->ptr[j]; d[j] = b->dst[j]; nb[j] = 0;
-        if (act >> j & 1) nb[j] = ((((uint32_t)p[j][-1] << 8) | p[j][0]) >> (8 - kExtra)) & 0xff;
+        pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = 0;
+        if (act >> j & 1) w0[j] = window_at(pw[j]);
     }
-    // the byte every lane would shift in next: bits of the stream starting 7 bits into ptr[-1] (rangecod.c:297-299)
-    __m512i nextbits = _mm512_load_si512(nb);
+    __m512i win = _mm512_load_si512(w0);
+    __m512i cnt = _mm512_set1_epi32(4);
+    const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
     alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
     __m128i rows[16];
 
@@ -69,16 +80,21 @@ void vec_decode_block(VecBlock* b, VecOther other)
         // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
         while (sh) {
-            low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), nextbits);
+            low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            unsigned m = sh;
-            do {
-                const int j = __builtin_ctz(m);
-                m &= m - 1;
-                const uint8_t* q = ++p[j];
-                const uint32_t v = ((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff;
-                nextbits = _mm512_mask_set1_epi32(nextbits, (__mmask16)(1u << j), (int)v);
-            } while (m);
+            win = _mm512_mask_slli_epi32(win, sh, win, 8);
+            cnt = _mm512_mask_sub_epi32(cnt, sh, cnt, one);
+            unsigned m = _mm512_mask_cmpeq_epu32_mask(sh & act, cnt, _mm512_setzero_si512());
+            if (__builtin_expect(m != 0, 0)) {
+                cnt = _mm512_mask_mov_epi32(cnt, (__mmask16)m, four);
+                do {
+                    const int j = __builtin_ctz(m);
+                    m &= m - 1;
+                    pw[j] += 4;
+                    win = _mm512_mask_set1_epi32(win, (__mmask16)(1u << j), (int)window_at(pw[j]));
+                } while (m);
+            }
+            cnt = _mm512_mask_mov_epi32(cnt, (__mmask16)(sh & ~act), four);  // idle lanes never run dry
             sh = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256, rare
         }
         // ---- help = range / 60000 (rangecod.c:312)
@@ -132,7 +148,10 @@ void vec_decode_block(VecBlock* b, VecOther other)
     }
     _mm512_mask_storeu_epi32(b->low, act, low);
     _mm512_mask_storeu_epi32(b->range, act, range);
-    for (int j = 0; j < kVecLanes; j++) b->ptr[j] = p[j];
+    alignas(64) uint32_t left[kVecLanes];
+    _mm512_store_si512(left, cnt);
+    for (int j = 0; j < kVecLanes; j++)
+        if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
 }
 
 }  // namespace wrrc
