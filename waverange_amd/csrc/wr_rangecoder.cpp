@@ -787,7 +787,7 @@ public:
     template <class OnEnd>
     void step(OnEnd on_end)
     {
-        constexpr size_t kMargin = 3 * (size_t)kBlock + 8;
+        constexpr size_t kMargin = 3 * (size_t)kBlock + 32;  // a symbol pulls in at most 3 bytes; the vector loop reads two windows ahead
         bool vec[kCap];
         for (int k = 0; k < count_;) {
             Dec& d = *ds_[k];

@@ -55,22 +55,24 @@ void vec_decode_block(VecBlock* b, VecOther other)
 
     // Byte feed.  The stream enters `low` as a bit string that starts 7 bits into the byte held back
     // (rangecod.c:297-299): the byte a lane shifts in at pointer q is ((q[-1] << 8 | q[0]) >> 1) & 0xff.  Every lane
-    // keeps a window of the next four such bytes (top byte first) and the count of those still unused; a lane
-    // whose window runs empty reloads it from its stream, four bytes ahead -- a scalar step per lane, but only
-    // every fourth byte it consumes.
-    const uint8_t* pw[kVecLanes];  // stream position the lane's window was loaded at
+    // keeps a window of the next four such bytes (top byte first), the count of those still unused, and the
+    // window after that, already loaded: when a window runs empty the next one takes its place with one vector
+    // move, and the scalar reload of the window after it (load, byte swap, general register -> vector lane:
+    // ~25 cycles) is not needed before the lane has consumed four more bytes -- it stays off the loop's
+    // dependency chain, which the whole-register update of a just-in-time reload would sit on.
+    const uint8_t* pw[kVecLanes];  // stream position the lane's current window was loaded at
     uint8_t* d[kVecLanes];
-    alignas(64) uint32_t w0[kVecLanes];
+    alignas(64) uint32_t w0[kVecLanes], w1[kVecLanes];
     auto window_at = [](const uint8_t* q) -> uint32_t {
         uint64_t v;
         __builtin_memcpy(&v, q - 1, 8);
         return (uint32_t)(__builtin_bswap64(v) >> 25);
     };
     for (int j = 0; j < kVecLanes; j++) {
-        pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = 0;
-        if (act >> j & 1) w0[j] = window_at(pw[j]);
+        pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = w1[j] = 0;
+        if (act >> j & 1) { w0[j] = window_at(pw[j]); w1[j] = window_at(pw[j] + 4); }
     }
-    __m512i win = _mm512_load_si512(w0);
+    __m512i win = _mm512_load_si512(w0), nxt = _mm512_load_si512(w1);
     __m512i cnt = _mm512_set1_epi32(4);
     const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
     alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
@@ -79,23 +81,25 @@ void vec_decode_block(VecBlock* b, VecOther other)
     for (uint32_t i = 0; i < kBlockSyms; i++) {
         // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
-        while (sh) {
+        for (;;) {
             low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
             win = _mm512_mask_slli_epi32(win, sh, win, 8);
             cnt = _mm512_mask_sub_epi32(cnt, sh, cnt, one);
-            unsigned m = _mm512_mask_cmpeq_epu32_mask(sh & act, cnt, _mm512_setzero_si512());
-            if (__builtin_expect(m != 0, 0)) {
-                cnt = _mm512_mask_mov_epi32(cnt, (__mmask16)m, four);
-                do {
+            const __mmask16 dry = _mm512_cmpeq_epu32_mask(cnt, _mm512_setzero_si512());
+            if (dry) {
+                win = _mm512_mask_mov_epi32(win, dry, nxt);
+                cnt = _mm512_mask_mov_epi32(cnt, dry, four);
+                unsigned m = dry & act;
+                while (m) {
                     const int j = __builtin_ctz(m);
                     m &= m - 1;
                     pw[j] += 4;
-                    win = _mm512_mask_set1_epi32(win, (__mmask16)(1u << j), (int)window_at(pw[j]));
-                } while (m);
+                    nxt = _mm512_mask_set1_epi32(nxt, (__mmask16)(1u << j), (int)window_at(pw[j] + 4));
+                }
             }
-            cnt = _mm512_mask_mov_epi32(cnt, (__mmask16)(sh & ~act), four);  // idle lanes never run dry
             sh = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256, rare
+            if (__builtin_expect(sh == 0, 1)) break;
         }
         // ---- help = range / 60000 (rangecod.c:312)
         const __m512i n5 = _mm512_srli_epi32(range, 5);
