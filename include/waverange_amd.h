@@ -269,9 +269,12 @@ int wr_range_encode_pool(int count, const unsigned char *const *sym, const size_
 int wr_range_decode_pool(int count, const unsigned char *const *in, const size_t *len,
                          unsigned char *const *sym, const size_t *n, size_t *produced);
 
-/* `count` planes on the calling thread through the 16-lane AVX-512 decoder loop for dominant-symbol planes (any
- * plane decodes correctly, the others just gain nothing); WR_ERR_UNSUPPORTED on a CPU without AVX-512.  The coder
- * pool routes planes below 2 bits per symbol there by itself. */
+/* `count` planes on the calling thread through the 16-lane AVX-512 loops: the encoder's takes planes of any kind,
+ * the decoder's gains on dominant-symbol planes (any plane decodes correctly, the others just gain nothing);
+ * WR_ERR_UNSUPPORTED on a CPU without AVX-512.  The coder pool routes all encoder planes and the decoder planes
+ * below 2 bits per symbol there by itself. */
+int wr_range_encode_vec(int count, const unsigned char *const *sym, const size_t *n,
+                        unsigned char *const *out, size_t *lens);
 int wr_range_decode_vec(int count, const unsigned char *const *in, const size_t *len,
                         unsigned char *const *sym, const size_t *n, size_t *produced);
 

@@ -72,3 +72,17 @@ for k in (4, 8, 12, 16):
         except api.WaveRangeError as exc:
             print("AVX-512 loop:", exc)
             break
+
+
+# the 16-lane AVX-512 encoder loop (any kind of plane; one thread)
+for k in (4, 8, 16):
+    for kind in ("noise", "two", "one"):
+        ps = [plane(kind) for _ in range(k)]
+        best = 1e9
+        try:
+            for _ in range(3):
+                t = time.time(); api.range_encode_vec(ps); best = min(best, time.time() - t)
+            print("AVX-512 encoder loop, %2d planes of kind %-5s encode %7.1f Msym/s per thread" % (k, kind, k * n / best / 1e6), flush=True)
+        except api.WaveRangeError as exc:
+            print("AVX-512 encoder loop:", exc)
+            break

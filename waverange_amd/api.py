@@ -128,6 +128,7 @@ def lib():
     L.wr_range_encode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_range_decode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_decode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.wr_range_encode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_bench_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     # drop-in symbols (reference src/core/wrappers.h:53,70,75)
     L.setup_wr.argtypes = [C.c_int] * 3 + [_u8p, _ulp]
@@ -260,6 +261,17 @@ def range_decode_pool(streams, ns):
     _check(lib().wr_range_decode_pool(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
                                       (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*ns), got))
     return [o[:n] for o, n in zip(outs, ns)], [got[i] for i in range(k)]
+
+
+def range_encode_vec(planes):
+    """Planes of any kind and length through the 16-lane AVX-512 encoder loop on this thread."""
+    ps = [np.ascontiguousarray(p, dtype=np.uint8).ravel() for p in planes]
+    k = len(ps)
+    outs = [np.empty(lib().wr_range_encode_bound(p.size), dtype=np.uint8) for p in ps]
+    lens = (C.c_size_t * k)()
+    _check(lib().wr_range_encode_vec(k, (C.c_void_p * k)(*[p.ctypes.data for p in ps]), (C.c_size_t * k)(*[p.size for p in ps]),
+                                     (C.c_void_p * k)(*[o.ctypes.data for o in outs]), lens))
+    return [o[:lens[i]].copy() for i, o in enumerate(outs)]
 
 
 def range_decode_vec(streams, ns):

@@ -1473,6 +1473,12 @@ int wr_range_decode_vec(int count, const unsigned char* const* in, const size_t*
     return WR_OK;
 }
 
+int wr_range_encode_vec(int count, const unsigned char* const* sym, const size_t* n, unsigned char* const* out, size_t* lens)
+{
+    if (!wrrc::encode_planes_vec(count, sym, n, out, lens)) return fail(WR_ERR_UNSUPPORTED, "this CPU has no AVX-512");
+    return WR_OK;
+}
+
 int wr_range_encode_pool(int count, const unsigned char* const* sym, const size_t* n, unsigned char* const* out, size_t* lens)
 {
     if (wrrc::pool_threads() < 1) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");

@@ -322,6 +322,94 @@ private:
 
 }  // namespace
 
+namespace {
+
+// Up to 16 encoder streams of any kind advancing block by block in lockstep on one thread: the symbols of the
+// full blocks are coded 16 lanes at a time by the AVX-512 loop (wr_rangecoder_vec.h), block headers and the
+// final partial block by the scalar code of their stream.
+class VecEncGroup {
+public:
+    static constexpr int kCap = kVecLanes;
+    VecEncGroup() { memset(tabs_, 0, sizeof tabs_); }
+    int count() const { return count_; }
+    bool full() const { return count_ == kCap; }
+    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag)
+    {
+        const int k = count_++;
+        es_[k] = new (store_[k]) Enc(out);
+        st_[k] = EncGroup::Stream{sym, n, 0, 0, hist, tag};
+    }
+    template <class OnEnd>
+    void step(OnEnd on_end)
+    {
+        uint32_t bs[kCap];
+        VecEncBlock vb;
+        vb.active = 0;
+        vb.tab = &tabs_[0][0].lt;
+        for (int k = 0; k < count_; k++) {
+            EncGroup::Stream& s = st_[k];
+            const size_t left = s.n - s.done;
+            bs[k] = left < kBlock ? (uint32_t)left : kBlock;
+            const uint8_t* ss = s.sym + s.done;
+            encode_block_header(*es_[k], ss, bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
+            if (bs[k] == kBlock) {
+                vb.active |= 1u << k;
+                vb.low[k] = es_[k]->low; vb.range[k] = es_[k]->range;
+                vb.sym[k] = ss; vb.out[k] = es_[k]->out; vb.pos[k] = es_[k]->pos; vb.top[k] = tops_[k];
+            } else if (bs[k]) {
+                encode_symbols<0, true>(*es_[k], ss, bs[k], tabs_[k], tops_[k]);
+            }
+        }
+        if (vb.active) {
+            for (int k = 0; k < kCap; k++)
+                if (!(vb.active >> k & 1)) { vb.low[k] = 0; vb.range[k] = 0; vb.sym[k] = nullptr; vb.out[k] = nullptr; vb.pos[k] = 0; vb.top[k] = 0xffffffffu; }
+            vec_encode_block(&vb);
+            for (int k = 0; k < count_; k++)
+                if (vb.active >> k & 1) { es_[k]->low = vb.low[k]; es_[k]->range = vb.range[k]; es_[k]->pos = vb.pos[k]; }
+        }
+        for (int k = 0; k < count_;) {
+            st_[k].done += bs[k];
+            st_[k].blk++;
+            if (bs[k] == kBlock) { k++; continue; }
+            es_[k]->freq(1, 0, 2);  // "no more blocks"
+            on_end(st_[k].tag, es_[k]->finish());
+            const int last = --count_;
+            if (k != last) {
+                es_[k] = new (store_[k]) Enc(*es_[last]);
+                st_[k] = st_[last];
+                bs[k] = bs[last];
+            }
+        }
+    }
+
+private:
+    int count_ = 0;
+    Enc* es_[kCap];
+    alignas(Enc) unsigned char store_[kCap][sizeof(Enc)];
+    EncGroup::Stream st_[kCap];
+    SymEntry tabs_[kCap][256];  // contiguous: the vector loop gathers {lt, sy} at (lane * 256 + symbol)
+    uint32_t tops_[kCap];
+};
+
+}  // namespace
+
+// `count` planes (any lengths, any statistics) on the calling thread through the 16-lane encoder loop: test and
+// measurement hook; the coder pool is the product path.  False if the CPU lacks AVX-512.
+bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, uint8_t* const* out, size_t* lens)
+{
+    if (!vec_available()) return false;
+    std::unique_ptr<VecEncGroup> g(new VecEncGroup);
+    int next = 0;
+    while (next < count || g->count()) {
+        while (next < count && !g->full()) {
+            g->add(sym[next], n[next], out[next], nullptr, lens + next);
+            next++;
+        }
+        g->step([](void* tag, size_t len) { *static_cast<size_t*>(tag) = len; });
+    }
+    return true;
+}
+
 void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens)
 {
     // up to kMaxEncStreams planes at a time in one symbol loop; further planes join as earlier ones end
@@ -973,7 +1061,9 @@ public:
             // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
             const bool vec = jobs[i].kind == PlaneJob::kDecode && vec_ok_ && jobs[i].n >= 4 * (size_t)kBlock &&
                              8 * jobs[i].src_len < 2 * jobs[i].n;
-            (vec ? vec_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
+            // the encoder's vector loop takes planes of any kind
+            const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock;
+            (vec ? vec_q_ : venc ? venc_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
         if (count > 1) cv_.notify_all(); else cv_.notify_one();
@@ -981,7 +1071,7 @@ public:
     ~Pool() { resize(0, 0); }
 
 private:
-    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2 };
+    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2, kVecEnc = 3 };
     // kAny: vector-decode jobs first (one worker absorbs up to 16 of them), then decode, then encode
     PlaneJob* pop(bool block, int want, int* got = nullptr)
     {
@@ -995,6 +1085,10 @@ private:
             if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
             if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max_) {
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
+            }
+            if (want == kVecEnc && !venc_q_.empty()) { PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); return j; }
+            if (want == kAny && !venc_q_.empty() && venc_sessions_ < venc_sessions_max_) {
+                PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); venc_sessions_++; if (got) *got = kVecEnc; return j;
             }
             if ((want == kAny || want == kDec) && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); if (got) *got = kDec; return j; }
             if ((want == kAny || want == kEnc) && !enc_q_.empty()) { PlaneJob* j = enc_q_.front(); enc_q_.pop_front(); if (got) *got = kEnc; return j; }
@@ -1017,6 +1111,7 @@ private:
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
         std::unique_ptr<DecGroup> dg;
         std::unique_ptr<VecDecGroup> vg;
+        std::unique_ptr<VecEncGroup> veg;
         EncGroup eg;
         struct Tag { PlaneJob* job; double t0; };
         Tag tags[kVecLanes];
@@ -1042,6 +1137,20 @@ private:
                 }
                 { std::lock_guard<std::mutex> lk(mu_); vec_sessions_--; }
                 cv_.notify_all();  // vector jobs queued meanwhile may start a session of their own now
+            } else if (kind == kVecEnc) {
+                if (!veg) veg.reset(new VecEncGroup);
+                while (j || veg->count()) {
+                    while (j) {
+                        Tag* t = free_tag();
+                        t->job = j; t->t0 = now_s();
+                        veg->add(j->src, j->n, j->dst, j->hist, t);
+                        j = veg->full() ? nullptr : pop(false, kVecEnc);
+                    }
+                    veg->step(on_end);
+                    if (!veg->full()) j = pop(false, kVecEnc);
+                }
+                { std::lock_guard<std::mutex> lk(mu_); venc_sessions_--; }
+                cv_.notify_all();
             } else if (kind == kDec) {
                 if (!dg) dg.reset(new DecGroup(dec_streams));
                 while (j || dg->count()) {
@@ -1071,7 +1180,10 @@ private:
 
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_;
+    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_;
+    const bool vec_enc_ = !(getenv("WR_VEC_ENCODE") && !atoi(getenv("WR_VEC_ENCODE")));
+    int venc_sessions_ = 0;
+    const int venc_sessions_max_ = getenv("WR_VEC_ENC_SESSIONS") ? atoi(getenv("WR_VEC_ENC_SESSIONS")) : 64;
     const bool vec_ok_ = vec_available();
     int vec_sessions_ = 0;
     const int vec_sessions_max_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 64;

@@ -43,6 +43,10 @@ void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8
 // (wr_rangecoder_vec.h); false if the CPU lacks AVX-512.  Same symbols as decode_plane on each.
 bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced);
 
+// `count` planes of any kind on the calling thread, up to 16 at a time in the AVX-512 encoder loop; false if the CPU
+// lacks AVX-512.  Same bytes as encode_plane on each.
+bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, uint8_t* const* out, size_t* lens);
+
 // ---- process-wide coder pool: plane streams of ALL concurrent encode / decode calls are coded by a fixed set
 // of worker threads.  A worker interleaves up to 3 encoder or up to `dec_streams` (<= kMaxDecStreams) decoder
 // streams in one symbol loop, whichever fields they belong to; streams join at block boundaries as others

@@ -158,4 +158,69 @@ void vec_decode_block(VecBlock* b, VecOther other)
         if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
 }
 
+void vec_encode_block(VecEncBlock* b)
+{
+    const __mmask16 act = (__mmask16)b->active;
+    const __m512i vbottom = _mm512_set1_epi32((int)kBottom), vtopm1 = _mm512_set1_epi32((int)(kTop - 1));
+    __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
+    __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
+    const __m512i top = _mm512_loadu_si512(b->top);
+    const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
+    const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
+    // table index of symbol c in lane j: (j * 256 + c) * 2 (+1 for sy), in 32-bit words
+    const __m512i lane_base = _mm512_mullo_epi32(_mm512_set_epi32(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0), _mm512_set1_epi32(512));
+    const int* tab = reinterpret_cast<const int*>(b->tab);
+
+    uint8_t* out[kVecLanes];
+    size_t pos[kVecLanes];
+    const uint8_t* in[kVecLanes];
+    static const uint8_t zeros[16] = {0};
+    for (int j = 0; j < kVecLanes; j++) { out[j] = b->out[j]; pos[j] = b->pos[j]; in[j] = (act >> j & 1) ? b->sym[j] : zeros; }
+    alignas(16) uint8_t bytes[16];
+    __m128i rows[16];
+
+    for (uint32_t i = 0; i < kBlockSyms; i++) {
+        // ---- symbols in: every 16 steps, 16 bytes of each plane, transposed to one row per step
+        if ((i & 15) == 0) {
+            for (int j = 0; j < kVecLanes; j++) rows[j] = _mm_loadu_si128(reinterpret_cast<const __m128i*>((act >> j & 1) ? in[j] + i : zeros));
+            transpose16x16(rows);
+        }
+        const __m512i c = _mm512_cvtepu8_epi32(rows[i & 15]);
+        // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom put a byte out
+        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
+        while (sh) {
+            _mm_store_si128(reinterpret_cast<__m128i*>(bytes), _mm512_cvtepi32_epi8(_mm512_srli_epi32(low, 23)));
+            const unsigned carry = _mm512_mask_test_epi32_mask(sh, low, _mm512_set1_epi32((int)kTop));
+            unsigned m = sh;
+            do {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                if (__builtin_expect(carry >> j & 1, 0)) {  // "carry now", rangecod.c:191-195
+                    size_t p = pos[j] - 1;
+                    while (++out[j][p] == 0) p--;
+                }
+                out[j][pos[j]++] = bytes[j];
+            } while (m);
+            low = _mm512_mask_and_epi32(low, sh, _mm512_slli_epi32(low, 8), vtopm1);
+            range = _mm512_mask_slli_epi32(range, sh, range, 8);
+            sh = _mm512_cmple_epu32_mask(range, vbottom) & act;  // a second byte: symbol probability < 1/256
+        }
+        // ---- r = range / 60000; low += r * lt; range = r * sy, or what is left for the largest symbol (rangecod.c:217-229)
+        const __m512i n5 = _mm512_srli_epi32(range, 5);
+        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
+        const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
+        const __m512i r = _mm512_or_si512(ev, od);
+        const __m512i idx = _mm512_add_epi32(lane_base, _mm512_slli_epi32(c, 1));
+        const __m512i lt = _mm512_i32gather_epi32(idx, tab, 4);
+        const __m512i sy = _mm512_i32gather_epi32(idx, tab + 1, 4);
+        const __m512i t = _mm512_mullo_epi32(r, lt);
+        low = _mm512_add_epi32(low, t);
+        const __mmask16 is_top = _mm512_cmpeq_epu32_mask(c, top);
+        range = _mm512_mask_sub_epi32(_mm512_mullo_epi32(r, sy), is_top, range, t);
+    }
+    _mm512_mask_storeu_epi32(b->low, act, low);
+    _mm512_mask_storeu_epi32(b->range, act, range);
+    for (int j = 0; j < kVecLanes; j++) b->pos[j] = pos[j];
+}
+
 }  // namespace wrrc

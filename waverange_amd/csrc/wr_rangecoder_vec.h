@@ -30,6 +30,20 @@ struct VecBlock {
 // symbol outside the candidates (rare): the scalar look-up path on that lane's model
 typedef uint32_t (*VecOther)(const void* model, uint32_t* low, uint32_t* range, uint32_t help);
 
+// One full block (60000 symbols) of up to 16 ENCODER streams, any symbol statistics: the encoder's dependency chain
+// is only renormalise -> range / 60000 -> new range (rangecod.c:182-229); the symbol's {lt, sy} come from a
+// gather into the lanes' tables, off that chain, and bytes leave per lane as they are produced.
+struct VecEncBlock {
+    uint32_t active;                 // lane mask
+    uint32_t low[kVecLanes], range[kVecLanes];
+    const uint8_t* sym[kVecLanes];   // 60000 symbols each
+    uint8_t* out[kVecLanes];         // stream buffers
+    size_t pos[kVecLanes];           // bytes written so far (>= 1: a carry walks back from out[pos - 1])
+    const uint32_t* tab;             // [16 lanes][256 symbols]{lt, sy}
+    uint32_t top[kVecLanes];         // largest symbol present: its interval is open-ended (rangecod.c:227)
+};
+void vec_encode_block(VecEncBlock* b);
+
 bool vec_available();  // the CPU has AVX-512 F/BW/DQ/VL and WR_NO_AVX512 is not set
 void vec_decode_block(VecBlock* b, VecOther other);
 
