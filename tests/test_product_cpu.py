@@ -270,9 +270,19 @@ def test_avx512_decoder_loop_same_symbols(oracle):
         pytest.skip("no AVX-512 on this CPU")
     for i, (d, g, p) in enumerate(zip(dec, got, planes)):
         assert g == p.size and np.array_equal(d, p), (i, p.size)
-    # through the pool as well (planes below 2 bits per symbol take the vector route there)
+    # the encoder's vector loop (candidate compares; rare other symbols through the lane's table; noise planes and
+    # partial blocks through the scalar code of their stream)
+    planes.append(np.where(rs.random_sample(300000) < 0.995, 255, rs.randint(0, 256, 300000)).astype(np.uint8))
+    enc.append(oracle.range_encode(planes[-1]))
+    venc = api.range_encode_vec(planes)
+    for i, (a, b) in enumerate(zip(venc, enc)):
+        assert np.array_equal(a, b), ("vector encode", i, planes[i].size)
+    # through the pool as well (dominant-symbol planes take the vector routes there)
     api.set_coder_pool(2, 4)
     try:
+        penc = api.range_encode_pool(planes)
+        for i, (a, b) in enumerate(zip(penc, enc)):
+            assert np.array_equal(a, b), ("pool encode", i, planes[i].size)
         dec, got = api.range_decode_pool(enc, [p.size for p in planes])
         for i, (d, g, p) in enumerate(zip(dec, got, planes)):
             assert g == p.size and np.array_equal(d, p), ("pool", i, p.size)

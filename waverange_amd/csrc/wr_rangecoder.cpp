@@ -324,9 +324,9 @@ private:
 
 namespace {
 
-// Up to 16 encoder streams of any kind advancing block by block in lockstep on one thread: the symbols of the
-// full blocks are coded 16 lanes at a time by the AVX-512 loop (wr_rangecoder_vec.h), block headers and the
-// final partial block by the scalar code of their stream.
+// Up to 16 encoder streams advancing block by block in lockstep on one thread: the full blocks that at most four
+// symbols hold (>= 99 %) are coded 16 lanes at a time by the AVX-512 loop (wr_rangecoder_vec.h), block headers,
+// other blocks and the final partial block by the scalar code of their stream.
 class VecEncGroup {
 public:
     static constexpr int kCap = kVecLanes;
@@ -352,17 +352,40 @@ public:
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
             const uint8_t* ss = s.sym + s.done;
             encode_block_header(*es_[k], ss, bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
-            if (bs[k] == kBlock) {
+            // the four most frequent symbols of the block; the vector loop takes the block if they hold >= 99 % of it
+            uint32_t cand[kVecCand], covered = 0;
+            for (int e = 0; e < kVecCand; e++) {
+                int best = -1;
+                for (int v = 0; v < 256; v++) {
+                    if (!tabs_[k][v].sy || (best >= 0 && tabs_[k][v].sy <= tabs_[k][best].sy)) continue;
+                    bool used = false;
+                    for (int f = 0; f < e; f++) used = used || cand[f] == (uint32_t)v;
+                    if (!used) best = v;
+                }
+                cand[e] = best < 0 ? 0x100u : (uint32_t)best;
+                if (best >= 0) covered += tabs_[k][best].sy;
+            }
+            if (bs[k] == kBlock && (uint64_t)covered * 100 >= (uint64_t)kBlock * 99) {
                 vb.active |= 1u << k;
                 vb.low[k] = es_[k]->low; vb.range[k] = es_[k]->range;
                 vb.sym[k] = ss; vb.out[k] = es_[k]->out; vb.pos[k] = es_[k]->pos; vb.top[k] = tops_[k];
+                for (int e = 0; e < kVecCand; e++) {
+                    vb.cand[e][k] = cand[e];
+                    vb.lt[e][k] = cand[e] < 256 ? tabs_[k][cand[e]].lt : 0;
+                    vb.sy[e][k] = cand[e] < 256 ? tabs_[k][cand[e]].sy : 0;
+                }
+            } else if (bs[k] == kBlock) {
+                encode_symbols<kBlock, true>(*es_[k], ss, kBlock, tabs_[k], tops_[k]);
             } else if (bs[k]) {
                 encode_symbols<0, true>(*es_[k], ss, bs[k], tabs_[k], tops_[k]);
             }
         }
         if (vb.active) {
             for (int k = 0; k < kCap; k++)
-                if (!(vb.active >> k & 1)) { vb.low[k] = 0; vb.range[k] = 0; vb.sym[k] = nullptr; vb.out[k] = nullptr; vb.pos[k] = 0; vb.top[k] = 0xffffffffu; }
+                if (!(vb.active >> k & 1)) {
+                    vb.low[k] = 0; vb.range[k] = 0; vb.sym[k] = nullptr; vb.out[k] = nullptr; vb.pos[k] = 0; vb.top[k] = 0xffffffffu;
+                    for (int e = 0; e < kVecCand; e++) { vb.cand[e][k] = 0x100; vb.lt[e][k] = 0; vb.sy[e][k] = 0; }
+                }
             vec_encode_block(&vb);
             for (int k = 0; k < count_; k++)
                 if (vb.active >> k & 1) { es_[k]->low = vb.low[k]; es_[k]->range = vb.range[k]; es_[k]->pos = vb.pos[k]; }
@@ -1027,6 +1050,25 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
 // =====================================================================================
 namespace {
 
+// do at most four symbols hold >= 99 % of the blocks of this plane?  (eight blocks across the plane are looked at)
+bool few_symbol_plane(const PlaneJob& j)
+{
+    const size_t nblocks = j.n / kBlock;
+    for (int s = 0; s < 8; s++) {
+        const size_t blk = nblocks * (size_t)s / 8;
+        uint32_t h[256];
+        if (j.hist) for (int v = 0; v < 256; v++) h[v] = j.hist[blk * 256 + v];
+        else histogram(j.src + blk * kBlock, kBlock, h);
+        uint32_t top4[4] = {0, 0, 0, 0};
+        for (int v = 0; v < 256; v++) {
+            uint32_t x = h[v];
+            for (int e = 0; e < 4; e++) if (x > top4[e]) { const uint32_t t = top4[e]; top4[e] = x; x = t; }
+        }
+        if ((uint64_t)(top4[0] + top4[1] + top4[2] + top4[3]) * 100 < (uint64_t)kBlock * 99) return false;
+    }
+    return true;
+}
+
 class Pool {
 public:
     static Pool& get() { static Pool p; return p; }
@@ -1061,8 +1103,9 @@ public:
             // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
             const bool vec = jobs[i].kind == PlaneJob::kDecode && vec_ok_ && jobs[i].n >= 4 * (size_t)kBlock &&
                              8 * jobs[i].src_len < 2 * jobs[i].n;
-            // the encoder's vector loop takes planes of any kind
-            const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock;
+            // encoder: planes whose blocks at most four symbols hold (sampled) take the vector loop
+            const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock &&
+                              few_symbol_plane(jobs[i]);
             (vec ? vec_q_ : venc ? venc_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }

@@ -165,11 +165,14 @@ void vec_encode_block(VecEncBlock* b)
     __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
     __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
     const __m512i top = _mm512_loadu_si512(b->top);
+    __m512i cand[kVecCand], clt[kVecCand], csy[kVecCand];
+    for (int e = 0; e < kVecCand; e++) {
+        cand[e] = _mm512_mask_loadu_epi32(_mm512_set1_epi32(0x100), act, b->cand[e]);
+        clt[e] = _mm512_maskz_loadu_epi32(act, b->lt[e]);
+        csy[e] = _mm512_maskz_loadu_epi32(act, b->sy[e]);
+    }
     const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
     const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
-    // table index of symbol c in lane j: (j * 256 + c) * 2 (+1 for sy), in 32-bit words
-    const __m512i lane_base = _mm512_mullo_epi32(_mm512_set_epi32(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0), _mm512_set1_epi32(512));
-    const int* tab = reinterpret_cast<const int*>(b->tab);
 
     uint8_t* out[kVecLanes];
     size_t pos[kVecLanes];
@@ -177,6 +180,7 @@ void vec_encode_block(VecEncBlock* b)
     static const uint8_t zeros[16] = {0};
     for (int j = 0; j < kVecLanes; j++) { out[j] = b->out[j]; pos[j] = b->pos[j]; in[j] = (act >> j & 1) ? b->sym[j] : zeros; }
     alignas(16) uint8_t bytes[16];
+    alignas(64) uint32_t tc[kVecLanes];
     __m128i rows[16];
 
     for (uint32_t i = 0; i < kBlockSyms; i++) {
@@ -186,6 +190,22 @@ void vec_encode_block(VecEncBlock* b)
             transpose16x16(rows);
         }
         const __m512i c = _mm512_cvtepu8_epi32(rows[i & 15]);
+        // ---- {lt, sy} of the symbol: one of the lane's candidates, else the lane's table
+        const __mmask16 k1 = _mm512_cmpeq_epu32_mask(c, cand[1]), k2 = _mm512_cmpeq_epu32_mask(c, cand[2]), k3 = _mm512_cmpeq_epu32_mask(c, cand[3]);
+        const __mmask16 k0 = _mm512_cmpeq_epu32_mask(c, cand[0]);
+        __m512i lt = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(_mm512_mask_mov_epi32(clt[0], k1, clt[1]), k2, clt[2]), k3, clt[3]);
+        __m512i sy = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(_mm512_mask_mov_epi32(csy[0], k1, csy[1]), k2, csy[2]), k3, csy[3]);
+        unsigned miss = act & ~(k0 | k1 | k2 | k3);
+        if (__builtin_expect(miss != 0, 0)) {
+            _mm512_store_si512(tc, c);
+            do {
+                const int j = __builtin_ctz(miss);
+                miss &= miss - 1;
+                const uint32_t* e = b->tab + ((size_t)j * 256 + tc[j]) * 2;
+                lt = _mm512_mask_set1_epi32(lt, (__mmask16)(1u << j), (int)e[0]);
+                sy = _mm512_mask_set1_epi32(sy, (__mmask16)(1u << j), (int)e[1]);
+            } while (miss);
+        }
         // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom put a byte out
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
         while (sh) {
@@ -210,9 +230,6 @@ void vec_encode_block(VecEncBlock* b)
         const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
         const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
         const __m512i r = _mm512_or_si512(ev, od);
-        const __m512i idx = _mm512_add_epi32(lane_base, _mm512_slli_epi32(c, 1));
-        const __m512i lt = _mm512_i32gather_epi32(idx, tab, 4);
-        const __m512i sy = _mm512_i32gather_epi32(idx, tab + 1, 4);
         const __m512i t = _mm512_mullo_epi32(r, lt);
         low = _mm512_add_epi32(low, t);
         const __mmask16 is_top = _mm512_cmpeq_epu32_mask(c, top);

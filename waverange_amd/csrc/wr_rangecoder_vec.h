@@ -30,16 +30,20 @@ struct VecBlock {
 // symbol outside the candidates (rare): the scalar look-up path on that lane's model
 typedef uint32_t (*VecOther)(const void* model, uint32_t* low, uint32_t* range, uint32_t help);
 
-// One full block (60000 symbols) of up to 16 ENCODER streams, any symbol statistics: the encoder's dependency chain
-// is only renormalise -> range / 60000 -> new range (rangecod.c:182-229); the symbol's {lt, sy} come from a
-// gather into the lanes' tables, off that chain, and bytes leave per lane as they are produced.
+// One full block (60000 symbols) of up to 16 ENCODER streams whose blocks are held by at most four symbols (all but a
+// per cent or less): the encoder's dependency chain is only renormalise -> range / 60000 -> new range
+// (rangecod.c:182-229); the symbol's {lt, sy} come from four compares against the lane's candidates, a symbol outside
+// them takes a scalar table look-up on that lane; bytes leave per lane as they are produced.  (With gathers into the
+// lanes' tables instead of the compares the loop takes any plane, but was measured slower than the scalar loops on
+// all but the most skewed planes: two 16-lane gathers per step cost more than the whole scalar step.)
 struct VecEncBlock {
     uint32_t active;                 // lane mask
     uint32_t low[kVecLanes], range[kVecLanes];
     const uint8_t* sym[kVecLanes];   // 60000 symbols each
     uint8_t* out[kVecLanes];         // stream buffers
     size_t pos[kVecLanes];           // bytes written so far (>= 1: a carry walks back from out[pos - 1])
-    const uint32_t* tab;             // [16 lanes][256 symbols]{lt, sy}
+    uint32_t cand[kVecCand][kVecLanes], lt[kVecCand][kVecLanes], sy[kVecCand][kVecLanes];  // unused entries: cand = 0x100
+    const uint32_t* tab;             // [16 lanes][256 symbols]{lt, sy}: symbols outside the candidates
     uint32_t top[kVecLanes];         // largest symbol present: its interval is open-ended (rangecod.c:227)
 };
 void vec_encode_block(VecEncBlock* b);
