@@ -277,7 +277,8 @@ def test_avx512_decoder_loop_same_symbols(oracle):
     venc = api.range_encode_vec(planes)
     for i, (a, b) in enumerate(zip(venc, enc)):
         assert np.array_equal(a, b), ("vector encode", i, planes[i].size)
-    # through the pool as well (dominant-symbol planes take the vector routes there)
+    # through the pool as well (dominant-symbol planes take the decoder's vector route there; the encoder's is
+    # opt-in with WR_VEC_ENCODE=1, read when the pool object is created: covered by the native harness)
     api.set_coder_pool(2, 4)
     try:
         penc = api.range_encode_pool(planes)
