@@ -97,7 +97,7 @@ def take_cpu_share(local_rank, gpus_on_node):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True):
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -122,12 +122,16 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
             mem = min(mem, int(m[0])) if mem else int(m[0])
     # 2 coder threads per field; an encoder thread idles a third of the time (decoding takes longer and
     # sets the period of a lane), hence 1.25 threads per CPU
-    by_cpu = int(1.25 * cpus // (2 * ntols))
+    # with the coder pool the lanes are not threads: one field in flight per CPU keeps the pool's queues full
+    by_cpu = int(cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
     # host memory per field in flight: pinned plane staging of the two contexts + coded streams (1.4 field sizes,
     # measured 1.32) + the pinned output field (host-to-host mode); HBM: the work-space slots only, or
     # (resident mode) two field buffers per lane on top
-    per_lane = (2.45 if host_mode else 1.4) * field_bytes
-    by_mem = int((0.8 * mem / local_world - (field_bytes if host_mode else 0)) // (per_lane * ntols)) if mem else want
+    # (host mode: the output fields come from a small pool -- two-phase decode -- so a lane costs its plane staging and
+    # coded streams only; the input field and the output pool are a fixed 1 + out_pool field sizes)
+    per_lane = 1.4 * field_bytes
+    fixed = (1 + out_pool) * field_bytes if host_mode else 0
+    by_mem = int((0.8 * mem / local_world - fixed) // (per_lane * ntols)) if mem else want
     by_hbm = want if host_mode else int((0.92 * hbm_free - 3 * 3.3 * field_bytes) // (2 * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / local_world / 2 ** 30, 1) if mem else None,
@@ -206,7 +210,8 @@ def main():
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=5, help="fields in flight per tolerance (a step codes jobs x tols fields)")
+    ap.add_argument("--jobs", type=int, default=8, help="fields in flight per tolerance (a step codes jobs x tols fields); cut down to what the rank's CPUs and memory allow")
+    ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
     ap.add_argument("--resident", action="store_true", help="fields start and end in HBM (round-1 measurement) instead of host buffers")
@@ -260,7 +265,8 @@ def main():
     # ~2.45 field sizes of host memory per field (pinned plane staging, coded streams, the pinned output field).
     # --jobs is the upper bound.
     share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
-    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode)
+    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
+                            pooled=args.pool != 0, out_pool=args.out_buffers)
     limits["cpu_affinity_share"] = share
     pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
     if pool_workers:
@@ -296,11 +302,27 @@ def main():
         ce = ctx if i == 0 else api.Context(dev_index)
         cd = api.Context(dev_index)
         ln = dict(tol=tol, enc=ce, dec=cd, data=[np.empty(cap, dtype=np.uint8) for _ in range(2)])
-        if host_mode:
-            ln["out"] = host_field()
-        else:
+        if not host_mode:
             ln["work"], ln["rec"] = ce.alloc(nelem * 8), cd.alloc(nelem * 8)
         lanes.append(ln)
+
+    # host mode: the reconstructions land in one of a few pinned output fields, borrowed for the device half of a
+    # decode only (wr_decode_begin / wr_decode_finish_host); the last reconstruction of the last lane is checked
+    # against the input before its buffer goes back
+    import queue
+    out_pool = queue.Queue()
+    if host_mode:
+        for _ in range(max(1, min(args.out_buffers, len(lanes)))):
+            out_pool.put(host_field())
+    accuracy = {}
+
+    def linf_vs_input(out):
+        diff = amax = 0.0
+        for z in range(0, n, 64):  # in slabs: no field-sized temporaries
+            a, b = h_in[z:z + 64], out[z:z + 64]
+            diff = max(diff, float(np.abs(a - b).max()))
+            amax = max(amax, float(np.abs(a).max()))
+        return diff / amax
 
     stats = {t: {} for t in tols}
     keys = ("fwd_ms", "inv_ms", "quant_ms", "dequant_ms", "minmax_ms", "enc_s", "dec_s", "enc_rc_s", "dec_rc_s", "enc_gpu_s",
@@ -340,8 +362,19 @@ def main():
                         if errors:
                             return
                         enc, te = box[k & 1]
-                        td = ln["dec"].decode_host(ln["out"], enc) if host_mode else ln["dec"].decode(ln["rec"], shape, enc)
-                        free[k & 1].release()
+                        if host_mode:
+                            ln["dec"].decode_begin(shape, enc)       # host range decoding: seconds, no field buffer
+                            free[k & 1].release()                    # the coded stream is not needed any more
+                            out = out_pool.get()
+                            try:
+                                td = ln["dec"].decode_finish_host(out)  # upload, kernels, download: ~0.25 s
+                                if record and ln is lanes[-1] and k == nsteps - 1:
+                                    accuracy["linf_rel"] = linf_vs_input(out)
+                            finally:
+                                out_pool.put(out)
+                        else:
+                            td = ln["dec"].decode(ln["rec"], shape, enc)
+                            free[k & 1].release()
                         if record:
                             with lock:
                                 for key, val in (("fwd_ms", te["transform_ms"]), ("inv_ms", td["transform_ms"]), ("quant_ms", te["quant_ms"]),
@@ -380,14 +413,10 @@ def main():
 
     # accuracy of the last reconstruction (tols[-1]) against the original
     if host_mode:
-        diff = amax = 0.0
-        for z in range(0, n, 64):  # in slabs: no field-sized temporaries
-            a, b = h_in[z:z + 64], lanes[-1]["out"][z:z + 64]
-            diff = max(diff, float(np.abs(a - b).max()))
-            amax = max(amax, float(np.abs(a).max()))
+        linf_rel = accuracy.get("linf_rel")
     else:
         diff, amax = lanes[-1]["dec"].linf(orig, lanes[-1]["rec"], nelem)
-    linf_rel = diff / amax
+        linf_rel = diff / amax
 
     mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
     if rank == 0:
@@ -418,7 +447,7 @@ def main():
                                       "BASELINE configs[2]" if n == 1024 else
                                       ("BASELINE configs[3]: independent 512^3 fields sharded one per GPU" if world > 1 else "BASELINE configs[1]") if n == 512
                                       else "parity-size run"),
-                       "boundary": "host buffers (pinned), wr_encode_host / wr_decode_host" if host_mode else "device buffers, wr_encode_device / wr_decode_device",
+                       "boundary": "host buffers (pinned), wr_encode_host / wr_decode_begin + wr_decode_finish_host (%d output fields shared by the lanes)" % out_pool.qsize() if host_mode else "device buffers, wr_encode_device / wr_decode_device",
                        "field_shards": world,
                        "range_coder": ({"pool_workers": pool_workers, "decoder_streams_per_loop": args.dec_streams, "encoder_streams_per_loop": 3} if pool_workers
                                        else {"threads_per_call": {"encode": args.enc_threads or args.threads, "decode": args.threads}}),
@@ -466,8 +495,9 @@ def main():
             api.set_threads(8)
             ln = lanes[-1]
             if host_mode:
+                out1 = out_pool.get()
                 enc1, te1 = ln["enc"].encode_host(h_in, ln["tol"], out=ln["data"][0])
-                td1 = ln["dec"].decode_host(ln["out"], enc1)
+                td1 = ln["dec"].decode_host(out1, enc1)
             else:
                 ln["enc"].copy(ln["work"], orig, nelem * 8)
                 enc1, te1 = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][0])

@@ -342,3 +342,38 @@ def test_coder_pool_codes_all_fields_in_flight(api, oracle):
     finally:
         api.set_coder_pool(0)
     assert not errors, errors
+
+
+def test_two_phase_decode(ctx, api, oracle):
+    """wr_decode_begin (host range decoding, no field buffer) + wr_decode_finish_host / _device (upload, kernels,
+    download): same reconstruction as the one-call decode, with per-call coder threads and with the pool; the
+    coded bytes may be dropped after begin; a finish without a begin is an error."""
+    f = synth.field(180, 190, 200, seed=21)
+    want = oracle.encode(f, 1e-7)
+    rec = oracle.decode(want, f.shape)
+    for pool in (0, 3):
+        api.set_coder_pool(pool)
+        try:
+            enc = dict(want)
+            enc["data"] = want["data"].copy()
+            ctx.decode_begin(f.shape, enc)
+            enc["data"][:] = 0          # not needed any more
+            out = np.full(f.shape, -1.0)
+            ctx.decode_finish_host(out)
+            assert bits_equal(out, rec)
+            ctx.decode_begin(f.shape, want)
+            buf = ctx.alloc(f.nbytes)
+            ctx.decode_finish(buf)
+            assert bits_equal(buf.download(np.float64, f.size), rec)
+            buf.free()
+        finally:
+            api.set_coder_pool(0)
+    with pytest.raises(api.WaveRangeError, match="without a wr_decode_begin"):
+        ctx.decode_finish_host(np.empty(f.shape))
+    # trivial field through the two calls
+    g = np.full((4, 5, 6), 2.5)
+    e, _ = ctx.encode_host(g, 1e-6)
+    ctx.decode_begin(g.shape, e)
+    out = np.zeros_like(g)
+    ctx.decode_finish_host(out)
+    assert np.array_equal(out, g)

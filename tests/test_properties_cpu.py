@@ -64,6 +64,9 @@ def test_bench_batch_sizing():
     # host buffer to host buffer (the default): HBM holds only the slots, host memory is what a lane costs
     jobs, lim = bench.fit_jobs(5, 2, fb, 288 * 10 ** 9)
     assert 1 <= jobs <= 5 and lim["jobs_by_hbm"] == 5 and jobs <= max(1, lim["jobs_by_host_mem"])
+    # with the coder pool a lane is not a thread: one field in flight per CPU
+    jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True)
+    assert lim["jobs_by_cpu"] == int(lim["cpus_per_rank"] // 2)
 
 
 def test_bench_cpu_share_pinning():

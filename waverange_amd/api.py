@@ -108,6 +108,9 @@ def lib():
     L.wr_decode_host.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(EncInfo), _vp, C.c_size_t,
                                  C.POINTER(Timings)]
     L.wr_transform_host.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.wr_decode_begin.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(EncInfo), _vp, C.c_size_t, C.POINTER(Timings)]
+    L.wr_decode_finish_host.argtypes = [_vp, _vp, C.POINTER(Timings)]
+    L.wr_decode_finish_device.argtypes = [_vp, _vp, C.POINTER(Timings)]
     L.wr_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
     L.wr_host_free.argtypes = [_vp]
     L.wr_set_device_slots.argtypes = [C.c_int, C.c_int]
@@ -510,6 +513,29 @@ class Context:
             data = np.zeros(1, dtype=np.uint8)
         _check(lib().wr_decode_host(self.h, out.ctypes.data, nx, ny, nz, C.byref(info), data.ctypes.data, data.size,
                                     C.byref(tm)))
+        return tm.as_dict()
+
+    def decode_begin(self, shape, enc):
+        """Host half of a decode (range decoding into the context's staging); no output buffer needed yet."""
+        nz, ny, nx = shape
+        info = EncInfo.from_dict(enc)
+        tm = Timings()
+        data = np.ascontiguousarray(enc["data"], dtype=np.uint8)
+        if data.size == 0:
+            data = np.zeros(1, dtype=np.uint8)
+        _check(lib().wr_decode_begin(self.h, nx, ny, nz, C.byref(info), data.ctypes.data, data.size, C.byref(tm)))
+        return tm.as_dict()
+
+    def decode_finish_host(self, out):
+        """Device half of the decode begun on this context: upload, kernels, download into `out`."""
+        assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+        tm = Timings()
+        _check(lib().wr_decode_finish_host(self.h, out.ctypes.data, C.byref(tm)))
+        return tm.as_dict()
+
+    def decode_finish(self, buf):
+        tm = Timings()
+        _check(lib().wr_decode_finish_device(self.h, buf.ptr, C.byref(tm)))
         return tm.as_dict()
 
     def transform_host(self, fld, lvl):

@@ -172,6 +172,11 @@ struct wr_ctx {
         std::mutex mu;               // several threads may wait for the same transfer
     };
     Xfer x_field, x_plane[WR_NLAYMAX];
+    // two-phase decode (wr_decode_begin / wr_decode_finish_*): the planes are decoded and wait in h_plane
+    bool pend_valid = false;
+    wr_enc_info pend_info;
+    int pend_nx = 0, pend_ny = 0, pend_nz = 0;
+    wr_timings pend_tm;
     std::mutex mu;
 };
 
@@ -1219,35 +1224,48 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     return WR_OK;
 }
 
+// mode: the whole decode; or only its host half (range decoding into the context's plane staging, no field buffer
+// needed: wr_decode_begin); or only its device half on planes decoded before (wr_decode_finish_*)
+enum DecodeMode { kDecodeWhole, kDecodeBegin, kDecodeFinish };
+
 int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_info* info, const unsigned char* data_enc,
-                size_t data_len, wr_timings* tm)
+                size_t data_len, wr_timings* tm, DecodeMode mode = kDecodeWhole)
 {
     if (int rc = ctx_bind(c)) return rc;
-    if (int rc = check_dims(nx, ny, nz, fld.dev)) return rc;
-    if (!fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
     std::lock_guard<std::mutex> lk(c->mu);
+    if (mode == kDecodeFinish) {
+        if (!c->pend_valid) return fail(WR_ERR_ARG, "wr_decode_finish without a wr_decode_begin on this context");
+        info = &c->pend_info; nx = c->pend_nx; ny = c->pend_ny; nz = c->pend_nz;
+        c->pend_valid = false;
+    }
+    if (int rc = check_dims(nx, ny, nz, fld.dev)) return rc;
+    if (mode != kDecodeBegin && !fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
     const size_t pitch = wr_plane_pitch(n);
     wr_timings local; memset(&local, 0, sizeof local);
+    if (mode == kDecodeFinish) local = c->pend_tm;
     DevPool* const pool = c->pool;
+    if (mode == kDecodeBegin) { c->pend_info = *info; c->pend_nx = nx; c->pend_ny = ny; c->pend_nz = nz; }
     if (info->ntot_enc == 0) {  // wrappers.cpp:462-469
+        if (mode == kDecodeBegin) { c->pend_tm = local; c->pend_valid = true; if (tm) *tm = local; return WR_OK; }
         if (fld.host) for (size_t j = 0; j < n; j++) fld.host[j] = info->midval;
         else { wrk::fill(fld.dev, n, info->midval, c->stream); HIPCHK(hipStreamSynchronize(c->stream)); }
-        local.total = now() - t0;
+        local.total += now() - t0;
         if (tm) *tm = local;
         return WR_OK;
     }
     const int nlay = info->nlay;
     if (nlay < 1 || nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
     if (info->wlev != 0 && info->wlev != kWavLvl) return fail(WR_ERR_ARG, "wlev must be 0 or 4");
-    if (verbose()) printf("Range decoding...\n");
+    const bool host_half = mode != kDecodeFinish, device_half = mode != kDecodeBegin;
+    if (host_half && verbose()) printf("Range decoding...\n");
     for (int l = 0; l < nlay; l++) if (int rc = ensure_host_plane(c, l, pitch)) return rc;
 
     size_t off[WR_NLAYMAX + 1] = {0};
     for (int l = 0; l < nlay; l++) off[l + 1] = off[l] + info->len_enc_vec[l];
     if (off[nlay] > info->ntot_enc) return fail(WR_ERR_STREAM, "len_enc_vec exceeds ntot_enc");
-    if (data_len && info->ntot_enc > data_len) return fail(WR_ERR_STREAM, "ntot_enc exceeds the length of the coded buffer");
+    if (host_half && data_len && info->ntot_enc > data_len) return fail(WR_ERR_STREAM, "ntot_enc exceeds the length of the coded buffer");
 
     SlotNeed need;
     transform_need(nx, ny, nz, info->wlev ? -kWavLvl : 0, &need);
@@ -1262,12 +1280,12 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved, or the process-wide
     // coder pool (wr_set_coder_pool), whose workers interleave planes of several fields
     const bool pooled = wrrc::pool_threads() > 0;
-    const int groups = pooled ? 0 : std::min(nlay, coder_threads());
+    const int groups = (pooled || !host_half) ? 0 : std::min(nlay, coder_threads());
     int rc = WR_OK;
-    double t_phase = 0, t_coded = 0;
+    double t_phase = 0, t_coded = t0;
     try {
         SlotLease slot;
-        if (pooled) {
+        if (pooled && host_half) {
             wrrc::PlaneJob jobs[WR_NLAYMAX];
             wrrc::JobBatch batch;
             for (int l = 0; l < nlay; l++) {
@@ -1284,7 +1302,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         // are still being decoded; the accumulate kernel then consumes them in plane order
         // (wrappers.cpp:492-516 reorganised).  With grouped threads all planes of a group finish together,
         // and the slot is only claimed afterwards.
-        const bool early = groups == nlay && nlay > 1 && slot.acquire(c, need, /*nowait=*/true, /*spare=*/1) == WR_OK;
+        const bool early = mode == kDecodeWhole && groups == nlay && nlay > 1 && slot.acquire(c, need, /*nowait=*/true, /*spare=*/1) == WR_OK;
         if (early) g_stat[WR_STAT_EARLY_DECODES]++;
         auto upload_plane = [&](int l) -> int {
             const Piece pc = {slot->planes + l * pitch, c->h_plane[l], n};
@@ -1311,7 +1329,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
                 });
         }
         int bad = -1;
-        for (int l = 0; l < nlay; l++) {
+        for (int l = 0; l < nlay && host_half; l++) {
             if (got[l] != n) bad = l;
             if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
         }
@@ -1319,8 +1337,19 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             if (early) for (int l = 0; l < nlay; l++) (void)xfer_wait(&c->x_plane[l]);
             return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
         }
-        t_coded = now();
-        if (verbose()) {  // wrappers.cpp:489, 503-510
+        if (host_half) {
+            t_coded = now();
+            local.transfer = (t_coded - t0) - local.rangecoder;
+            if (local.transfer < 0) local.transfer = 0;
+        }
+        if (!device_half) {  // the planes wait in the context's staging for wr_decode_finish_*
+            local.total = now() - t0;
+            c->pend_tm = local;
+            c->pend_valid = true;
+            if (tm) *tm = local;
+            return WR_OK;
+        }
+        if (host_half && verbose()) {  // wrappers.cpp:489, 503-510
             for (int l = 0; l < nlay; l++) {
                 const uint8_t* q = c->h_plane[l];
                 unsigned lo = q[0], hi = q[0];
@@ -1370,10 +1399,9 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); local.quant_ms = ms;
     HIPCHK(hipEventElapsedTime(&ms, c->ev_b, c->ev_c)); local.transform_ms = ms;
-    local.total = now() - t0;
+    local.total += now() - t0;  // (a finish adds to what its begin took)
     local.gpu = now() - t_phase;  // without the wait for a slot
-    local.transfer = (t_coded - t0) - local.rangecoder;
-    if (local.transfer < 0) local.transfer = 0;
+    local.wait = t_phase - t_coded;
     if (tm) *tm = local;
     return WR_OK;
 }
@@ -1422,6 +1450,27 @@ int wr_decode_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, const wr_en
 {
     FieldRef f; f.host = h_fld;
     return decode_impl(c, f, nx, ny, nz, info, data_enc, data_len, tm);
+}
+
+int wr_decode_begin(wr_ctx* c, int nx, int ny, int nz, const wr_enc_info* info, const unsigned char* data_enc, size_t data_len,
+                    wr_timings* tm)
+{
+    FieldRef none;
+    return decode_impl(c, none, nx, ny, nz, info, data_enc, data_len, tm, kDecodeBegin);
+}
+
+int wr_decode_finish_host(wr_ctx* c, double* h_fld, wr_timings* tm)
+{
+    FieldRef f; f.host = h_fld;
+    if (!h_fld) return fail(WR_ERR_ARG, "null field pointer");
+    return decode_impl(c, f, 0, 0, 0, nullptr, nullptr, 0, tm, kDecodeFinish);
+}
+
+int wr_decode_finish_device(wr_ctx* c, double* d_fld, wr_timings* tm)
+{
+    FieldRef f; f.dev = d_fld;
+    if (!d_fld) return fail(WR_ERR_ARG, "null device field pointer");
+    return decode_impl(c, f, 0, 0, 0, nullptr, nullptr, 0, tm, kDecodeFinish);
 }
 
 int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
