@@ -1120,13 +1120,13 @@ private:
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            // at most vec_sessions_max_ workers run a vector session at a time (WR_VEC_SESSIONS; default: no limit
-            // that matters -- two sessions for all planes were measured: fewer CPUs busy, but every stream then
-            // advances at 1/16 of a loop that is latency-bound at ~75 cycles per step, and the fields in flight
-            // wait longer for their planes); what is queued beyond that joins a running session at its next
-            // block boundary
+            // at most vec_sessions_max() workers run a vector session at a time (WR_VEC_SESSIONS; default about a fifth
+            // of the workers): a session is worth its core with many lanes filled, so the dominant-symbol planes of
+            // all fields in flight are concentrated on a few workers (16 workers, 16 fields in flight, 40 such
+            // planes per step: 8.7 GB/s with three sessions, 8.4 with four, 8.2 without a limit, 6.8 with two, which
+            // cannot hold them all); what is queued beyond that joins a running session at its next block boundary
             if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
-            if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max_) {
+            if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max()) {
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
             }
             if (want == kVecEnc && !venc_q_.empty()) { PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); return j; }
@@ -1232,7 +1232,13 @@ private:
     const int venc_sessions_max_ = getenv("WR_VEC_ENC_SESSIONS") ? atoi(getenv("WR_VEC_ENC_SESSIONS")) : 64;
     const bool vec_ok_ = vec_available();
     int vec_sessions_ = 0;
-    const int vec_sessions_max_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 64;
+    const int vec_sessions_env_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 0;
+    int vec_sessions_max() const  // call with mu_ held
+    {
+        if (vec_sessions_env_ > 0) return vec_sessions_env_;
+        const int w = (int)workers_.size();
+        return w < 4 ? 1 : (w + 2) / 5;
+    }
     std::vector<std::thread> workers_;
     bool stop_ = false;
     int dec_streams_ = kMaxDecStreams;
