@@ -178,7 +178,11 @@ void vec_encode_block(VecEncBlock* b)
     size_t pos[kVecLanes];
     const uint8_t* in[kVecLanes];
     static const uint8_t zeros[16] = {0};
-    for (int j = 0; j < kVecLanes; j++) { out[j] = b->out[j]; pos[j] = b->pos[j]; in[j] = (act >> j & 1) ? b->sym[j] : zeros; }
+    uint8_t dummy[8];  // idle lanes store their byte here (and never advance)
+    for (int j = 0; j < kVecLanes; j++) {
+        const bool on = act >> j & 1;
+        out[j] = on ? b->out[j] : dummy; pos[j] = on ? b->pos[j] : 0; in[j] = on ? b->sym[j] : zeros;
+    }
     alignas(16) uint8_t bytes[16];
     alignas(64) uint32_t tc[kVecLanes];
     __m128i rows[16];
@@ -206,24 +210,30 @@ void vec_encode_block(VecEncBlock* b)
                 sy = _mm512_mask_set1_epi32(sy, (__mmask16)(1u << j), (int)e[1]);
             } while (miss);
         }
-        // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom put a byte out
+        // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom put a byte out.  Branch-free for the
+        // usual single byte: every lane stores its candidate byte at its write position and advances by 0 or 1
+        // (as the scalar loop does), so that no data-dependent branch or scalar loop count sits between one
+        // step's range and the next; a pending carry and a second byte (symbol probability < 1/256) are rare.
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
-        while (sh) {
+        for (;;) {
             _mm_store_si128(reinterpret_cast<__m128i*>(bytes), _mm512_cvtepi32_epi8(_mm512_srli_epi32(low, 23)));
-            const unsigned carry = _mm512_mask_test_epi32_mask(sh, low, _mm512_set1_epi32((int)kTop));
-            unsigned m = sh;
-            do {
-                const int j = __builtin_ctz(m);
-                m &= m - 1;
-                if (__builtin_expect(carry >> j & 1, 0)) {  // "carry now", rangecod.c:191-195
-                    size_t p = pos[j] - 1;
-                    while (++out[j][p] == 0) p--;
-                }
-                out[j][pos[j]++] = bytes[j];
-            } while (m);
+            unsigned carry = _mm512_mask_test_epi32_mask(sh, low, _mm512_set1_epi32((int)kTop));
+            while (__builtin_expect(carry != 0, 0)) {  // "carry now", rangecod.c:191-195
+                const int j = __builtin_ctz(carry);
+                carry &= carry - 1;
+                size_t p = pos[j] - 1;
+                while (++out[j][p] == 0) p--;
+            }
+            const unsigned m = sh;
+#pragma GCC unroll 16
+            for (int j = 0; j < kVecLanes; j++) {
+                out[j][pos[j]] = bytes[j];
+                pos[j] += m >> j & 1;
+            }
             low = _mm512_mask_and_epi32(low, sh, _mm512_slli_epi32(low, 8), vtopm1);
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            sh = _mm512_cmple_epu32_mask(range, vbottom) & act;  // a second byte: symbol probability < 1/256
+            sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
+            if (__builtin_expect(sh == 0, 1)) break;
         }
         // ---- r = range / 60000; low += r * lt; range = r * sy, or what is left for the largest symbol (rangecod.c:217-229)
         const __m512i n5 = _mm512_srli_epi32(range, 5);
@@ -237,7 +247,7 @@ void vec_encode_block(VecEncBlock* b)
     }
     _mm512_mask_storeu_epi32(b->low, act, low);
     _mm512_mask_storeu_epi32(b->range, act, range);
-    for (int j = 0; j < kVecLanes; j++) b->pos[j] = pos[j];
+    for (int j = 0; j < kVecLanes; j++) if (act >> j & 1) b->pos[j] = pos[j];
 }
 
 }  // namespace wrrc
