@@ -369,7 +369,7 @@ int xfer_start(wr_ctx* c, wr_ctx::Xfer* x, const Piece* pc, int count, Dir dir)
     return WR_OK;
 }
 
-// Waits for a transfer (no-op if none is pending).  May be called from any thread, once per start.
+// Waits for a transfer (no-op if none is pending).  May be called from any thread, any number of times.
 int xfer_wait(wr_ctx::Xfer* x)
 {
     std::lock_guard<std::mutex> lk(x->mu);
