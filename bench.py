@@ -97,7 +97,7 @@ def take_cpu_share(local_rank, gpus_on_node):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4):
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -110,6 +110,9 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
         cpus = min(cpus, float(q1[0]) / float(p1[0]))
     # with the affinity already cut down to this rank's share the count is per rank; quotas are per job
     cpus = min(float(pinned_share), cpus) if pinned_share else cpus / local_world
+    # host memory like the CPUs: a rank sizes itself to its GPU's share of the node whether 1 or 8 ranks run, so that
+    # the per-GPU work does not change with N (weak scaling measures GPUs, not how much idle memory one rank can borrow)
+    mem_share = max(local_world, gpus_on_node if pinned_share else 1)
     mem = None
     try:
         with open("/proc/meminfo") as fh:
@@ -131,10 +134,10 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # coded streams only; the input field and the output pool are a fixed 1 + out_pool field sizes)
     per_lane = 1.4 * field_bytes
     fixed = (1 + out_pool) * field_bytes if host_mode else 0
-    by_mem = int((0.8 * mem / local_world - fixed) // (per_lane * ntols)) if mem else want
+    by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
     by_hbm = want if host_mode else int((0.92 * hbm_free - 3 * 3.3 * field_bytes) // (2 * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
-    return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / local_world / 2 ** 30, 1) if mem else None,
+    return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / mem_share / 2 ** 30, 1) if mem else None,
                   "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
 
 
@@ -266,7 +269,7 @@ def main():
     # --jobs is the upper bound.
     share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
     jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
-                            pooled=args.pool != 0, out_pool=args.out_buffers)
+                            pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev)
     limits["cpu_affinity_share"] = share
     pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
     if pool_workers:
