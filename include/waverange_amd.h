@@ -134,8 +134,8 @@ typedef struct wr_timings {
     float minmax_ms;    /* stand-alone min/max reductions */
     double wait;        /* waiting for a free work-space slot of the device */
     float h2d_ms;       /* host entry points: upload of the field (encode) / the planes (decode) */
-    float d2h_ms;       /* first plane copy .. last copy of the call on the download stream (encode) /
-                           download of the field (decode) */
+    float d2h_ms;       /* host entry points: sum of the plane downloads (encode) / download of the field
+                           (decode); engine timestamps for DMA copies */
 } wr_timings;
 
 const char *wr_last_error(void);
