@@ -186,32 +186,31 @@ namespace {
 template <int NS, bool TOPSEL>
 inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const SymEntry (*tabs)[256], const uint32_t* tops)
 {
-    // per plane: low, range, the write pointer and the symbol pointer -- four general registers; with a separate
-    // buffer base and position it was five, and three planes did not fit the sixteen there are
     uint32_t low[NS], range[NS];
-    uint8_t* wp[NS];
-    for (int k = 0; k < NS; k++) { low[k] = es[k]->low; range[k] = es[k]->range; wp[k] = es[k]->out + es[k]->pos; }
+    uint8_t* out[NS];
+    size_t pos[NS];
+    for (int k = 0; k < NS; k++) { low[k] = es[k]->low; range[k] = es[k]->range; out[k] = es[k]->out; pos[k] = es[k]->pos; }
     for (uint32_t i = 0; i < kBlock; i++) {
 #pragma GCC unroll 8
         for (int k = 0; k < NS; k++) {
             const uint32_t c = ss[k][i];
             const uint32_t sh = range[k] <= kBottom;
             if (__builtin_expect(sh & (low[k] >> 31), 0)) {
-                uint8_t* p = wp[k] - 1;
-                while (++*p == 0) p--;
+                size_t p = pos[k] - 1;
+                while (++out[k][p] == 0) p--;
             }
-            *wp[k] = (uint8_t)(low[k] >> kShift);
-            wp[k] += sh;
+            out[k][pos[k]] = (uint8_t)(low[k] >> kShift);
+            pos[k] += sh;
             // conditional moves by hand: left to itself the compiler turns these selects into branches in
             // this loop, and on a plane of ~1 bit per symbol "a byte leaves now" is badly predicted
             low[k] = select_u32(sh, (low[k] << 8) & (kTop - 1), low[k]);
             range[k] = select_u32(sh, range[k] << 8, range[k]);
             while (__builtin_expect(range[k] <= kBottom, 0)) {
                 if (low[k] & kTop) {
-                    uint8_t* p = wp[k] - 1;
-                    while (++*p == 0) p--;
+                    size_t p = pos[k] - 1;
+                    while (++out[k][p] == 0) p--;
                 }
-                *wp[k]++ = (uint8_t)(low[k] >> kShift);
+                out[k][pos[k]++] = (uint8_t)(low[k] >> kShift);
                 range[k] <<= 8;
                 low[k] = (low[k] << 8) & (kTop - 1);
             }
@@ -222,7 +221,7 @@ inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const
                               : ((c != tops[k]) ? r * tabs[k][c].sy : range[k] - t);
         }
     }
-    for (int k = 0; k < NS; k++) { es[k]->low = low[k]; es[k]->range = range[k]; es[k]->pos = (size_t)(wp[k] - es[k]->out); }
+    for (int k = 0; k < NS; k++) { es[k]->low = low[k]; es[k]->range = range[k]; es[k]->pos = pos[k]; }
 }
 
 // block header of wrappers.cpp:85-113: "a block follows", then the 256 counts
