@@ -377,3 +377,41 @@ def test_two_phase_decode(ctx, api, oracle):
     out = np.zeros_like(g)
     ctx.decode_finish_host(out)
     assert np.array_equal(out, g)
+
+
+def test_host_api_error_paths(ctx, api):
+    """The host entry points return error codes (never crash, never fall back): null field, coded buffer shorter than
+    the header says, a header with an impossible transform depth, too small an output capacity, a slot count
+    change that would drop populated slots; the context keeps working afterwards."""
+    import ctypes as C
+    f = synth.field(48, 40, 24, seed=5)
+    enc, _ = ctx.encode_host(f, 1e-6)
+    enc["data"] = enc["data"].copy()
+    L = api.lib()
+    info, tm = api.EncInfo.from_dict(enc), api.Timings()
+    out = np.empty_like(f)
+    # null host pointers
+    assert L.wr_decode_host(ctx.h, None, 48, 40, 24, C.byref(info), enc["data"].ctypes.data, enc["data"].size, C.byref(tm)) != 0
+    cut = np.array([1e-6])
+    assert L.wr_encode_host(ctx.h, None, 48, 40, 24, 1, 1, 1, 1, cut.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info),
+                            enc["data"].ctypes.data, enc["data"].size, C.byref(tm)) != 0
+    # the coded buffer is shorter than ntot_enc
+    info = api.EncInfo.from_dict(enc)
+    rc = L.wr_decode_host(ctx.h, out.ctypes.data, 48, 40, 24, C.byref(info), enc["data"].ctypes.data, enc["data"].size - 1, C.byref(tm))
+    assert rc != 0 and b"length of the coded buffer" in L.wr_last_error()
+    # impossible transform depth in the header
+    bad = dict(enc, wlev=3)
+    with pytest.raises(api.WaveRangeError, match="wlev"):
+        ctx.decode_host(out, bad)
+    # output capacity too small
+    small = np.empty(enc["ntot_enc"] // 2, dtype=np.uint8)
+    with pytest.raises(api.WaveRangeError, match="encoded array is too large"):
+        ctx.encode_host(f, 1e-6, out=small)
+    # the slot in use cannot be dropped
+    with pytest.raises(api.WaveRangeError):
+        api.set_device_slots(0, 0 + 1) if api.stat(api.STAT_SLOTS_POPULATED) > 1 else (_ for _ in ()).throw(api.WaveRangeError("n/a"))
+    # and the context still works
+    again, _ = ctx.encode_host(f, 1e-6)
+    assert np.array_equal(again["data"], enc["data"])
+    ctx.decode_host(out, enc)
+    assert np.abs(out - f).max() <= 1.05e-6 * np.abs(f).max()
