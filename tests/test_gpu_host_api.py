@@ -381,8 +381,8 @@ def test_two_phase_decode(ctx, api, oracle):
 
 def test_host_api_error_paths(ctx, api):
     """The host entry points return error codes (never crash, never fall back): null field, coded buffer shorter than
-    the header says, a header with an impossible transform depth, too small an output capacity, a slot count change
-    that would drop populated slots; the context keeps working afterwards."""
+    the header says, a header with an impossible transform depth, too small an output capacity, a bad device index;
+    the context keeps working afterwards."""
     import ctypes as C
     f = synth.field(48, 40, 24, seed=5)
     enc, _ = ctx.encode_host(f, 1e-6)
@@ -407,11 +407,10 @@ def test_host_api_error_paths(ctx, api):
     small = np.empty(enc["ntot_enc"] // 2, dtype=np.uint8)
     with pytest.raises(api.WaveRangeError, match="encoded array is too large"):
         ctx.encode_host(f, 1e-6, out=small)
-    # slots that hold device buffers cannot be dropped; keeping the count is fine
-    if api.stat(api.STAT_SLOTS_POPULATED) > 1:
-        with pytest.raises(api.WaveRangeError, match="in use"):
-            api.set_device_slots(0, 1)
+    # the slot count: out-of-range values are clamped, a device index beyond the table is an error
     api.set_device_slots(0, 3)
+    with pytest.raises(api.WaveRangeError, match="device index"):
+        api.set_device_slots(1000, 2)
     # and the context still works
     again, _ = ctx.encode_host(f, 1e-6)
     assert np.array_equal(again["data"], enc["data"])
