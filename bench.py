@@ -3,20 +3,23 @@
 host buffer (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; % HBM roofline; L-inf vs
 tol"; SURVEY.md 8d(1): the reference API takes and returns host arrays).
 
-One step = one batch of jobs x len(tols) fields per GPU (default 5 x 2, fewer if the rank's CPUs or memory
-are short).  Every field starts in a pinned host buffer and is encoded (upload; min/max, forward CDF-9/7,
-bit-plane quantizer on the GPU; planes D2H; rngcod13 range coder on the host -> coded bytes in host memory)
-and decoded again (range decoder on the host; planes H2D; dequantise + inverse transform on the GPU;
-download into another pinned host buffer): wr_encode_host / wr_decode_host, the functions the drop-in
-encoding_wrap / decoding_wrap run on.  The range coder is one serial recurrence per plane and runs on the
-host by design, so the whole-job rate is set by the host cores a GPU has (16 on this pool): every field in
-flight gets one encoder and one decoder thread that code its 3-4 planes with interleaved symbol loops, and
-enough fields are in flight to fill the cores.  The device stages of the fields (upload / kernels / download,
-three work-space slots per GPU) overlap with one another and with the host coding inside the library.
+One step = one batch of jobs x len(tols) fields per GPU (default 8 x 2: one field in flight per CPU of the rank,
+fewer if its CPUs or host memory are short).  Every field starts in a pinned host buffer and is encoded
+(upload; min/max, forward CDF-9/7, bit-plane quantizer on the GPU; planes D2H; rngcod13 range coder on the
+host -> coded bytes in host memory: wr_encode_host, what the drop-in encoding_wrap runs on) and decoded again
+(range decoder on the host: wr_decode_begin; planes H2D; dequantise + inverse transform on the GPU; download
+into a pinned host buffer: wr_decode_finish_host -- decoding_wrap does the two in one call; in two calls the
+output field is only held for the last quarter second, so four output buffers serve all lanes).  The range
+coder is one serial recurrence per plane and runs on the host by design, so the whole-job rate is set by the
+host cores a GPU has (16 on this pool): the plane streams of all fields in flight go to a pool of one coder
+thread per CPU, whose workers interleave 3-4 streams of any fields per symbol loop (dominant-symbol planes 16
+at a time in an AVX-512 loop).  The device stages of the fields (upload / kernels / download, three work-space
+slots per GPU, copies on the SDMA engines) overlap with one another and with the host coding inside the library.
 value = field megabytes (10^6 B) round-tripped per second, whole job (all ranks).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 5] [--threads 1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 8] [--pool -1]
                   [--resident]   (fields start and end in HBM instead: the round-1 measurement)
+                  [--pool 0 --threads 1]   (no coder pool: every call codes its planes on its own thread)
 
 N > 1: one process per GPU (torch.distributed / RCCL for the timing barrier only); every rank
 codes its own independent field (seed 12345 + rank): weak scaling, no data-path collective.
