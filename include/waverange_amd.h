@@ -125,8 +125,9 @@ typedef struct wr_enc_info {
 /* per-call stage timings in seconds (host wall clock around the stages) */
 typedef struct wr_timings {
     double total;      /* whole call */
-    double gpu;        /* device kernels: min/max + transform + quantizer or dequant + inverse */
-    double transfer;   /* plane D2H / H2D not hidden behind the range coder */
+    double gpu;        /* the call's device phase: from getting a work-space slot to its last copy (upload,
+                          min/max + transform + quantizer or dequant + inverse, downloads) */
+    double transfer;   /* host time outside the range coder and the device phase (stream concatenation etc.) */
     double rangecoder; /* host range coder, wall time of the slowest plane thread */
     /* HIP-event durations on the context's stream, milliseconds */
     float transform_ms; /* all launches of the forward or inverse transform */
