@@ -193,6 +193,9 @@ int wr_host_alloc(void **ptr, size_t bytes);
 int wr_host_free(void *ptr);
 
 int wr_dev_copy(wr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* ctx stream, waits */
+/* measurement hook: copies through the compute units with `workgroups` workgroups on the context's stream, without
+ * waiting (either side may be pinned host memory; 16-byte granularity) */
+int wr_dev_copy_kernel(wr_ctx *ctx, void *dst, const void *src, size_t bytes, int workgroups);
 /* max|a-b| and max|a| over n doubles (accuracy check of a reconstruction, "L-inf vs tol") */
 int wr_dev_linf(wr_ctx *ctx, const double *d_a, const double *d_b, size_t n, double *max_abs_diff,
                 double *max_abs_a);

@@ -86,6 +86,7 @@ def lib():
     L.wr_dev_upload.argtypes = [_vp, _vp, _vp, C.c_size_t]
     L.wr_dev_download.argtypes = [_vp, _vp, _vp, C.c_size_t]
     L.wr_dev_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.wr_dev_copy_kernel.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
     L.wr_dev_linf.argtypes = [_vp, _vp, _vp, C.c_size_t, _dp, _dp]
     L.wr_dev_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.wr_dev_minmax.argtypes = [_vp, _vp, C.c_size_t, _dp, _dp]

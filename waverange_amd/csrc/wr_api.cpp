@@ -727,6 +727,15 @@ int wr_dev_download(wr_ctx* c, void* dst, const void* src, size_t bytes)
     return WR_OK;
 }
 
+int wr_dev_copy_kernel(wr_ctx* c, void* dst, const void* src, size_t bytes, int workgroups)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) || workgroups < 1) return fail(WR_ERR_ARG, "copy kernel: 16-byte granularity");
+    wrk::copy_kernel(dst, src, bytes, workgroups, c->stream);
+    HIPCHK(hipGetLastError());
+    return WR_OK;
+}
+
 int wr_dev_copy(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;

@@ -727,6 +727,24 @@ __global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, siz
     hist[(size_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)tot;
 }
 
+// Plain copy by a handful of workgroups: moves host <-> device data through the compute units instead of an SDMA
+// engine (pinned host memory is device-visible).  8-16 workgroups reach the PCIe rate (profiles/r02/c_d2h_probe.txt).
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+void copy_kernel(void* dst, const void* src, size_t bytes, int workgroups, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy16, dim3(workgroups), dim3(256), 0, st, static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16);
+}
+
 void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st)
 {
     const int nb = (int)(n / 60000 + 1);  // includes the (possibly empty) final block
