@@ -189,11 +189,18 @@ inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const
     uint32_t low[NS], range[NS];
     uint8_t* out[NS];
     size_t pos[NS];
-    for (int k = 0; k < NS; k++) { low[k] = es[k]->low; range[k] = es[k]->range; out[k] = es[k]->out; pos[k] = es[k]->pos; }
+    // local copies of the per-plane pointers and constants: the byte stores below may alias anything reached through
+    // a pointer (they are char stores), and would otherwise force ss[k] and tops[k] to be reloaded for every symbol
+    const uint8_t* sym[NS];
+    uint32_t top[NS];
+    for (int k = 0; k < NS; k++) {
+        low[k] = es[k]->low; range[k] = es[k]->range; out[k] = es[k]->out; pos[k] = es[k]->pos;
+        sym[k] = ss[k]; top[k] = tops[k];
+    }
     for (uint32_t i = 0; i < kBlock; i++) {
 #pragma GCC unroll 8
         for (int k = 0; k < NS; k++) {
-            const uint32_t c = ss[k][i];
+            const uint32_t c = sym[k][i];
             const uint32_t sh = range[k] <= kBottom;
             if (__builtin_expect(sh & (low[k] >> 31), 0)) {
                 size_t p = pos[k] - 1;
@@ -217,8 +224,8 @@ inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const
             const uint32_t r = range[k] / kBlock;
             const uint32_t t = r * tabs[k][c].lt;
             low[k] += t;
-            range[k] = TOPSEL ? select_u32(c ^ tops[k], r * tabs[k][c].sy, range[k] - t)
-                              : ((c != tops[k]) ? r * tabs[k][c].sy : range[k] - t);
+            range[k] = TOPSEL ? select_u32(c ^ top[k], r * tabs[k][c].sy, range[k] - t)
+                              : ((c != top[k]) ? r * tabs[k][c].sy : range[k] - t);
         }
     }
     for (int k = 0; k < NS; k++) { es[k]->low = low[k]; es[k]->range = range[k]; es[k]->pos = pos[k]; }
