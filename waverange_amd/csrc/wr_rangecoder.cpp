@@ -677,11 +677,18 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
     // through the model pointer where it is needed (hoisting it costs more in spills than it saves).
     uint32_t low[NS], range[NS];
     const uint8_t* p[NS];
-    for (int k = 0; k < NS; k++) { low[k] = ds[k]->low; range[k] = ds[k]->range; p[k] = ds[k]->in + ds[k]->pos; }
+    // local copies of the per-plane pointers: the symbol stores below are char stores, which may alias anything
+    // reached through a pointer, and would otherwise force ms[k] and dst[k] to be reloaded for every symbol
+    const BlockModel* mod[NS];
+    uint8_t* sym[NS];
+    for (int k = 0; k < NS; k++) {
+        low[k] = ds[k]->low; range[k] = ds[k]->range; p[k] = ds[k]->in + ds[k]->pos;
+        mod[k] = ms[k]; sym[k] = dst[k];
+    }
     for (uint32_t i = 0; i < kBlock; i++) {
 #pragma GCC unroll 8
         for (int k = 0; k < NS; k++) {
-            const BlockModel* const m = ms[k];
+            const BlockModel* const m = mod[k];
             uint32_t lw = low[k], rg = range[k];
             const uint8_t* q = p[k];
             {   // first renormalisation step without a branch
@@ -736,7 +743,7 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
                 lw -= t;
                 rg = (c != m->top) ? help * m->tab[c].sy : rg - t;
             }
-            dst[k][i] = (uint8_t)c;
+            sym[k][i] = (uint8_t)c;
             low[k] = lw; range[k] = rg; p[k] = q;
         }
     }
