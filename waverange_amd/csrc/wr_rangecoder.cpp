@@ -208,11 +208,10 @@ inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const
             }
             out[k][pos[k]] = (uint8_t)(low[k] >> kShift);
             pos[k] += sh;
-            // shifts by 0 or 8 instead of selects (no branch: on a plane of ~1 bit per symbol "a byte leaves now" is
-            // badly predicted; and fewer instructions than conditional moves): with sh = 1 the mask drops the
-            // bit that has just left as the top of the byte, with sh = 0 it keeps a pending carry bit
-            low[k] = (low[k] << (8 * sh)) & (0xffffffffu >> sh);
-            range[k] <<= 8 * sh;
+            // conditional moves by hand: left to itself the compiler turns these selects into branches in
+            // this loop, and on a plane of ~1 bit per symbol "a byte leaves now" is badly predicted
+            low[k] = select_u32(sh, (low[k] << 8) & (kTop - 1), low[k]);
+            range[k] = select_u32(sh, range[k] << 8, range[k]);
             while (__builtin_expect(range[k] <= kBottom, 0)) {
                 if (low[k] & kTop) {
                     size_t p = pos[k] - 1;
