@@ -105,14 +105,19 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     cpus = float(len(os.sched_getaffinity(0)))
+    quota = None  # CPU quota of the whole job (all ranks), if any
     q = _cgroup_number("/sys/fs/cgroup/cpu.max")  # cgroup v2
     if q and q[0] != "max":
-        cpus = min(cpus, float(q[0]) / float(q[1]))
+        quota = float(q[0]) / float(q[1])
     q1, p1 = _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_period_us")  # v1
     if q1 and p1 and float(q1[0]) > 0:
-        cpus = min(cpus, float(q1[0]) / float(p1[0]))
-    # with the affinity already cut down to this rank's share the count is per rank; quotas are per job
-    cpus = min(float(pinned_share), cpus) if pinned_share else cpus / local_world
+        quota = min(quota, float(q1[0]) / float(p1[0])) if quota else float(q1[0]) / float(p1[0])
+    if pinned_share:
+        # the affinity has been cut down to this rank's GPU's share of the node; a quota is split the same way,
+        # whether 1 or 8 ranks run
+        cpus = min(float(pinned_share), quota / gpus_on_node) if quota else float(pinned_share)
+    else:
+        cpus = (min(cpus, quota) if quota else cpus) / local_world
     # host memory like the CPUs: a rank sizes itself to its GPU's share of the node whether 1 or 8 ranks run, so that
     # the per-GPU work does not change with N (weak scaling measures GPUs, not how much idle memory one rank can borrow)
     mem_share = max(local_world, gpus_on_node if pinned_share else 1)
