@@ -169,11 +169,14 @@ int wr_set_device_slots(int device, int nslots);
 /* process-wide event counters (diagnostics and tests) */
 #define WR_STAT_EARLY_DECODES 0   /* decode calls that uploaded each plane as soon as it was decoded */
 #define WR_STAT_SLOTS_POPULATED 1 /* work-space slots that received device buffers */
+#define WR_STAT_STAGING_BYTES 2   /* host plane staging allocated right now (in use + idle), all devices */
 unsigned long wr_stat(int what);
 
-/* One context per concurrent caller: (device, kernel stream, pinned plane staging, coded-stream
- * buffers), grown on demand and kept.  The device work space is shared between the contexts of a
- * GPU (wr_set_device_slots).  stream == NULL makes the context create its own. */
+/* One context per concurrent caller: (device, kernel stream, coded-stream buffers), grown on demand
+ * and kept.  The device work space (wr_set_device_slots) and the pinned plane staging are shared
+ * between the contexts of a GPU: a call borrows one staging buffer per plane while the plane is on
+ * the host and returns it, so the staging held is that of the planes in flight, whatever the number
+ * of contexts.  stream == NULL makes the context create its own. */
 int wr_ctx_create(wr_ctx **ctx, int device, void *hip_stream);
 void wr_ctx_destroy(wr_ctx *ctx);
 int wr_ctx_sync(wr_ctx *ctx);

@@ -379,6 +379,39 @@ def test_two_phase_decode(ctx, api, oracle):
     assert np.array_equal(out, g)
 
 
+def test_plane_staging_is_shared_between_contexts(api, oracle):
+    """The pinned plane staging belongs to the device, not to the context: three contexts used one after the other
+    hold one set of buffers between them; planes parked by wr_decode_begin stay untouched while other contexts
+    borrow and return buffers, and go back to the pool after the finish."""
+    f = synth.field(96, 100, 104, seed=33)
+    g = synth.field(96, 100, 104, seed=34)
+    want_f, want_g = oracle.encode(f, 1e-7), oracle.encode(g, 1e-7)
+    pitch = (f.size + 255) // 256 * 256
+    base = api.stat(api.STAT_STAGING_BYTES)
+    ctxs = [api.Context(0) for _ in range(3)]
+    try:
+        for c in ctxs:
+            enc, _ = c.encode_host(f.copy(), 1e-7)
+            same_as_oracle(enc, want_f)
+        one_set = api.stat(api.STAT_STAGING_BYTES) - base
+        assert one_set <= (want_f["nlay"] + 1) * pitch, one_set         # at most one new set (idle buffers of earlier tests fit too), not three
+        ctxs[0].decode_begin(f.shape, want_f)                           # parks nlay planes in context 0
+        for c in ctxs[1:]:                                              # the others borrow different buffers meanwhile
+            enc, _ = c.encode_host(g.copy(), 1e-7)
+            same_as_oracle(enc, want_g)
+            out = np.empty(g.shape)
+            c.decode_host(out, want_g)
+            assert bits_equal(out, oracle.decode(want_g, g.shape))
+        out = np.empty(f.shape)
+        ctxs[0].decode_finish_host(out)
+        assert bits_equal(out, oracle.decode(want_f, f.shape))
+        two_sets = api.stat(api.STAT_STAGING_BYTES) - base
+        assert two_sets <= 2 * (max(want_f["nlay"], want_g["nlay"]) + 1) * pitch, two_sets
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_host_api_error_paths(ctx, api):
     """The host entry points return error codes (never crash, never fall back): null field, coded buffer shorter than
     the header says, a header with an impossible transform depth, too small an output capacity, a bad device index;

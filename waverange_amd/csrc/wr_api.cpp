@@ -133,6 +133,55 @@ constexpr int kMaxSlots = 4;
 // field staging, coefficients and planes, 1.2 GB of low-pass boxes; slots are populated on demand, so a
 // lone caller uses one), one copy stream per direction (copies of all contexts queue on them in call
 // order and stay off the streams that run kernels) and the stage locks.
+// Pinned host staging of quantized planes, shared by the contexts of one device: a call borrows one buffer per
+// plane for as long as the plane lives on the host (encode: download -> coded; decode: decoded -> uploaded) and
+// hands it back, so 16 fields in flight hold the planes in flight, not 16 x (encode set + decode set).
+struct PlaneStaging {
+    struct Buf { uint8_t* p = nullptr; size_t bytes = 0; bool pinned = false; };
+    std::mutex mu;
+    std::vector<Buf> idle;
+    static void release(const Buf& b) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
+    void drop_idle()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Buf& b : idle) { g_stat[WR_STAT_STAGING_BYTES] -= b.bytes; release(b); }
+        idle.clear();
+    }
+    // smallest idle buffer that holds `bytes` without being more than twice as large, else a new one
+    Buf take(size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); i++)
+                if (idle[i].bytes >= bytes && idle[i].bytes / 2 <= bytes && (best < 0 || idle[i].bytes < idle[best].bytes)) best = i;
+            if (best >= 0) { Buf b = idle[best]; idle[best] = idle.back(); idle.pop_back(); return b; }
+        }
+        Buf b;
+        b.bytes = bytes;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            drop_idle();  // buffers of another field size may be holding the pinned memory
+            if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+        }
+        if (q) { b.p = static_cast<uint8_t*>(q); b.pinned = true; }
+        else {
+            // no pinned memory left (many contexts of many ranks on one host): pageable staging works,
+            // the copy is then staged by the runtime and slower
+            b.p = static_cast<uint8_t*>(aligned_alloc(4096, (bytes + 4095) / 4096 * 4096));
+            b.pinned = false;
+        }
+        if (b.p) g_stat[WR_STAT_STAGING_BYTES] += bytes;
+        return b;
+    }
+    void give(const Buf& b)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.push_back(b);
+    }
+};
+
 struct DevPool {
     std::mutex mu; std::condition_variable cv;  // slot hand-out
     Slot slots[kMaxSlots];
@@ -140,6 +189,7 @@ struct DevPool {
     int users = 0;
     hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
+    PlaneStaging staging;
 };
 
 struct wr_ctx {
@@ -283,26 +333,35 @@ private:
 
 using StageLock = std::unique_lock<std::mutex>;
 
-// pinned staging of plane l, allocated the first time a field needs that many planes (a 1024^3
-// field at tol 1e-3 needs 3 GiB here, not 8)
+// pinned staging of plane l, borrowed from the device's pool the moment a field needs that plane (a 1024^3
+// field at tol 1e-3 borrows 3 GiB here, not 8) and handed back by the HostPlanes guard of the call
+void release_host_plane(wr_ctx* c, int l)
+{
+    if (!c->h_plane[l]) return;
+    PlaneStaging::Buf b; b.p = c->h_plane[l]; b.bytes = c->h_plane_bytes[l]; b.pinned = c->h_plane_pinned[l];
+    c->pool->staging.give(b);
+    c->h_plane[l] = nullptr; c->h_plane_bytes[l] = 0;
+}
+
 int ensure_host_plane(wr_ctx* c, int l, size_t bytes)
 {
-    if (c->h_plane_bytes[l] >= bytes) return WR_OK;
-    if (c->h_plane[l]) { if (c->h_plane_pinned[l]) HIPCHK(hipHostFree(c->h_plane[l])); else free(c->h_plane[l]); }
-    c->h_plane[l] = nullptr; c->h_plane_bytes[l] = 0;
-    if (hipHostMalloc(&c->h_plane[l], bytes, hipHostMallocDefault) == hipSuccess) {
-        c->h_plane_pinned[l] = true;
-    } else {
-        // no pinned memory left (many contexts of many ranks on one host): pageable staging works,
-        // the copy is then staged by the runtime and slower
-        (void)hipGetLastError();
-        c->h_plane[l] = static_cast<uint8_t*>(aligned_alloc(4096, (bytes + 4095) / 4096 * 4096));
-        c->h_plane_pinned[l] = false;
-        if (!c->h_plane[l]) return fail(WR_ERR_ARG, "out of host memory for the plane staging buffer");
-    }
-    c->h_plane_bytes[l] = bytes;
+    if (c->h_plane[l] && c->h_plane_bytes[l] >= bytes) return WR_OK;
+    release_host_plane(c, l);
+    const PlaneStaging::Buf b = c->pool->staging.take(bytes);
+    if (!b.p) return fail(WR_ERR_ARG, "out of host memory for the plane staging buffer");
+    c->h_plane[l] = b.p; c->h_plane_bytes[l] = b.bytes; c->h_plane_pinned[l] = b.pinned;
     return WR_OK;
 }
+
+// Declared before anything that may still touch the staging when the call unwinds (coder threads, transfers
+// are all waited for by then): returns the context's planes to the pool unless the call parks them
+// (wr_decode_begin keeps the decoded planes for wr_decode_finish_*).
+struct HostPlanes {
+    wr_ctx* c;
+    bool keep = false;
+    explicit HostPlanes(wr_ctx* ctx) : c(ctx) {}
+    ~HostPlanes() { if (!keep) for (int l = 0; l < WR_NLAYMAX; l++) release_host_plane(c, l); }
+};
 
 int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
 {
@@ -635,7 +694,7 @@ void wr_ctx_destroy(wr_ctx* c)
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_hist) (void)hipHostFree(c->h_hist);
     for (int l = 0; l < WR_NLAYMAX; l++) {
-        if (c->h_plane[l]) { if (c->h_plane_pinned[l]) (void)hipHostFree(c->h_plane[l]); else free(c->h_plane[l]); }
+        release_host_plane(c, l);
         free(c->enc_buf[l]);
     }
     for (int i = 0; i < WR_NLAYMAX; i++) {
@@ -657,6 +716,7 @@ void wr_ctx_destroy(wr_ctx* c)
             if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); p->up = nullptr; }
             if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); p->down = nullptr; }
             for (Slot& s : p->slots) s.release_buffers();
+            p->staging.drop_idle();
         }
     }
     delete c;
@@ -1062,6 +1122,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     std::string logs[WR_NLAYMAX];
     Sem sem(encoder_threads());
     const int dev = c->device;
+    HostPlanes staging(c);  // before the workers: they are joined first when the call unwinds
     Workers workers;
 
     // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
@@ -1269,6 +1330,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     if (info->wlev != 0 && info->wlev != kWavLvl) return fail(WR_ERR_ARG, "wlev must be 0 or 4");
     const bool host_half = mode != kDecodeFinish, device_half = mode != kDecodeBegin;
     if (host_half && verbose()) printf("Range decoding...\n");
+    HostPlanes staging(c);  // a finish finds the planes its begin parked in the context
     for (int l = 0; l < nlay; l++) if (int rc = ensure_host_plane(c, l, pitch)) return rc;
 
     size_t off[WR_NLAYMAX + 1] = {0};
@@ -1355,6 +1417,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             local.total = now() - t0;
             c->pend_tm = local;
             c->pend_valid = true;
+            staging.keep = true;
             if (tm) *tm = local;
             return WR_OK;
         }
