@@ -56,17 +56,20 @@ constexpr int NWAVE = NTHR / 64;
 constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (3)
 constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * 2 * TXP * 8;
 
-// blockIdx.x -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (b % 8
-// says which share an L2).  The plain row-major order gives every XCD one COLUMN of tiles when there
-// are 8 tile columns: y halos hit in L2, x halos never do.  Here an XCD gets a block 2 tiles wide
-// and tiles_y/2 tall instead, so half of the x halos are shared too (speed only: inverse -1.5 %).
+// blockIdx.x -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (b % 8 says which
+// share an L2), and the j-th workgroups of all XCDs run at the same time.  Tiles next to each other read the same
+// halo lines (x: the two 128-B lines a 68-column row segment sticks out into; y: 4 rows), which cost HBM traffic
+// unless the neighbour sits on the same L2.  An XCD therefore gets whole tile ROWS: tiles_y / 8 consecutive rows,
+// all columns -- no x halo leaves the XCD, and only the 4 halo rows at the band's two edges are fetched twice
+// (1024^3, level 0: 8 x 4 tiles per XCD, fetch 1.06 x the payload; a band 2 tiles wide and 16 tall: 1.26 x,
+// measured 10.84 GB for 8.59; one tile column per XCD, the plain order: 1.5 x).
 __device__ inline void tile_of_block(int b, int tiles_x, int tiles_y, int& tx, int& ty)
 {
 #ifndef WR_NO_XCD_BLOCK
-    if (tiles_x == 8 && (tiles_y & 1) == 0) {
+    if ((tiles_y & 7) == 0) {
         const int xcd = b & 7, j = b >> 3;  // j-th workgroup of this XCD
-        tx = 2 * (xcd & 3) + (j & 1);
-        ty = (xcd >> 2) * (tiles_y >> 1) + (j >> 1);
+        tx = j % tiles_x;
+        ty = xcd * (tiles_y >> 3) + j / tiles_x;
         return;
     }
 #endif
