@@ -25,7 +25,6 @@
 #include <stdlib.h>
 
 #include <mutex>
-#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -287,52 +286,44 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
         }
         // ---- z step: (a, b) is z-pair t  (waveletcdf97_3d.c:228-262).  Pair t-1 gets its first half
         // (last1 / first1: it is the last / first pair), pair t-2 its second half and leaves.
-        // Steps in the interior of the volume (and of the segment) run a copy of the step without the edge selects
-        // and range tests: ~10 % fewer vector instructions on all but 3 + 2 steps of a segment.
-        auto zstep = [&](auto edge_tag) {
-            constexpr bool EDGE = decltype(edge_tag)::value;
-            const bool last1 = EDGE && t - 1 >= m3 - 1, first1 = EDGE && t - 1 <= 0, last2 = EDGE && t - 2 >= m3 - 1,
-                       first2 = EDGE && t - 2 <= 0;
-            if (last1) {  // the pair after the last one mirrors it
+        const bool last1 = t - 1 >= m3 - 1, first1 = t - 1 <= 0, last2 = t - 2 >= m3 - 1, first2 = t - 2 <= 0;
+        if (last1) {  // the pair after the last one mirrors it
 #pragma unroll
-                for (int q = 0; q < 8; q++) a[q] = sr1[q];
+            for (int q = 0; q < 8; q++) a[q] = sr1[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            // Boundary forms by mirroring (c * (v + v) has the bits of (2 c) * v): one block-uniform select
+            // on an operand instead of the reference's second expression (waveletcdf97_3d.c:232,238,245,
+            // 251).  Pipeline fill / drain steps compute on zeros or stale values that never reach a store.
+            double D1 = 0, S1 = 0;
+            if (t >= 1 && t <= m3) {
+                D1 = dr1[q] + WR_ALPHA * (a[q] + sr1[q]);
+                S1 = sr1[q] + WR_BETA * (D1 + (first1 ? D1 : p1[q]));
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                // Boundary forms by mirroring (c * (v + v) has the bits of (2 c) * v): one block-uniform select
-                // on an operand instead of the reference's second expression (waveletcdf97_3d.c:232,238,245,
-                // 251).  Pipeline fill / drain steps compute on zeros or stale values that never reach a store.
-                double D1 = 0, S1 = 0;
-                if (!EDGE || (t >= 1 && t <= m3)) {
-                    D1 = dr1[q] + WR_ALPHA * (a[q] + sr1[q]);
-                    S1 = sr1[q] + WR_BETA * (D1 + (first1 ? D1 : p1[q]));
-                }
-                if (!EDGE || t >= 2) {
-                    const int j = t - 2;
-                    const double D2 = p1[q] + WR_GAMMA * ((last2 ? q1[q] : S1) + q1[q]);
-                    const double S2 = q1[q] + WR_DELTA * (D2 + (first2 ? D2 : p2[q]));
-                    const int yp = q >> 2;  // which of the two y-pairs
-                    // wave-uniform plane bases + per-lane 32-bit offsets (saddr form).  Trading values
-                    // between lane pairs for 16-byte stores was measured 3 % SLOWER (per-lane 64-bit
-                    // addresses, DPP + selects) -- profiles/r01/NOTES.md.
-                    if (own_x && oy + yp < m2 && (!EDGE || (j >= z0 && j < z1))) {
-                        double* base = dst + ((q & 1) ? oct_x : 0) + ((q & 2) ? oct_y : 0) + (size_t)yp * d_sy;
-                        const double clo = S2 * WR_ZETA, chi = D2 * WR_IZETA;
-                        if ((q & 3) == 0) (low + (size_t)j * l_sz + (size_t)yp * l_sy)[lpos] = clo;
-                        else (base + (size_t)j * d_sz)[pos0] = clo;
-                        (base + (size_t)(m3 + j) * d_sz)[pos0] = chi;
-                        if (MM_OUT) {
-                            out_lo = fmin(out_lo, chi); out_hi = fmax(out_hi, chi);
-                            if ((q & 3) != 0 || mm_lll) { out_lo = fmin(out_lo, clo); out_hi = fmax(out_hi, clo); }
-                        }
+            if (t >= 2) {
+                const int j = t - 2;
+                const double D2 = p1[q] + WR_GAMMA * ((last2 ? q1[q] : S1) + q1[q]);
+                const double S2 = q1[q] + WR_DELTA * (D2 + (first2 ? D2 : p2[q]));
+                const int yp = q >> 2;  // which of the two y-pairs
+                // wave-uniform plane bases + per-lane 32-bit offsets (saddr form).  Trading values
+                // between lane pairs for 16-byte stores was measured 3 % SLOWER (per-lane 64-bit
+                // addresses, DPP + selects) -- profiles/r01/NOTES.md.
+                if (own_x && oy + yp < m2 && j >= z0 && j < z1) {
+                    double* base = dst + ((q & 1) ? oct_x : 0) + ((q & 2) ? oct_y : 0) + (size_t)yp * d_sy;
+                    const double clo = S2 * WR_ZETA, chi = D2 * WR_IZETA;
+                    if ((q & 3) == 0) (low + (size_t)j * l_sz + (size_t)yp * l_sy)[lpos] = clo;
+                    else (base + (size_t)j * d_sz)[pos0] = clo;
+                    (base + (size_t)(m3 + j) * d_sz)[pos0] = chi;
+                    if (MM_OUT) {
+                        out_lo = fmin(out_lo, chi); out_hi = fmax(out_hi, chi);
+                        if ((q & 3) != 0 || mm_lll) { out_lo = fmin(out_lo, clo); out_hi = fmax(out_hi, clo); }
                     }
-                    p2[q] = D2;
                 }
-                p1[q] = D1; q1[q] = S1; sr1[q] = a[q]; dr1[q] = b[q];
+                p2[q] = D2;
             }
-        };
-        if (t >= 3 && t < m3 && t - 2 >= z0 && t - 2 < z1) zstep(std::false_type{});
-        else zstep(std::true_type{});
+            p1[q] = D1; q1[q] = S1; sr1[q] = a[q]; dr1[q] = b[q];
+        }
         STAMP(5);
     }
     if (MM_IN || MM_OUT) {
