@@ -413,10 +413,12 @@ def main():
     if args.warmup:
         run_steps(args.warmup, False)
     barrier()
+    cpu0 = sum(os.times()[:2])
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
     if dist is not None:
         t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -514,6 +516,7 @@ def main():
             out["host_peak_rss_gib"] = round(int(hwm[1]) / 2 ** 20, 2)
         except Exception:
             pass
+        out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
         if world == 1 and not args.no_cpu_baseline:
             # one field alone on the idle machine, a coder thread per plane: the latency a single
             # encoding_wrap / decoding_wrap caller sees (outside the timed region)

@@ -294,6 +294,15 @@ int wr_range_encode_vec(int count, const unsigned char *const *sym, const size_t
 int wr_range_decode_vec(int count, const unsigned char *const *in, const size_t *len,
                         unsigned char *const *sym, const size_t *n, size_t *produced);
 
+/* Test hooks for the windowed symbol path: planes that live in device memory reach the host coder through a small
+ * pinned ring, window by window (wr_encode_host / wr_decode_*); here the windows are `chunk` symbols (a multiple of
+ * 60000) of plain host buffers.  mode 0: interleaved loops on the calling thread, 1: the coder pool, 2: the 16-lane
+ * loops.  Same bytes / symbols as the whole-plane functions above. */
+int wr_range_encode_windowed(int mode, int count, const unsigned char *const *sym, size_t n, size_t chunk,
+                             unsigned char *const *out, size_t *lens);
+int wr_range_decode_windowed(int mode, int count, const unsigned char *const *in, const size_t *len,
+                             unsigned char *const *sym, size_t n, size_t chunk, size_t *produced);
+
 /* --- measurement hook for bench.py: runs `reps` forward (lvl>0) or inverse transforms of an
  * nx*ny*nz field back to back on the context's stream and returns the average duration of
  * one transform in milliseconds measured with HIP events on that stream. */

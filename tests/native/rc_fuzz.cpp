@@ -123,6 +123,72 @@ int main() {
         }
         wrrc::pool_configure(0, 0);
     }
+    // windowed symbol access (PlaneWindow): exact-size window buffers allocated afresh for every window, so ASan sees
+    // any access outside the window or to a window that was handed back
+    {
+        struct Win {
+            const uint8_t* plane; uint8_t* out; size_t n, chunk; uint8_t* cur; size_t cur_first, cur_count; bool dec;
+            static uint8_t* fn(void* u, size_t first, size_t* count)
+            {
+                Win* w = (Win*)u;
+                if (w->dec && w->cur) memcpy(w->out + w->cur_first, w->cur, w->cur_count);
+                delete[] w->cur; w->cur = nullptr;
+                if (*count == 0) return nullptr;
+                const size_t c = *count < w->chunk ? *count : w->chunk;
+                w->cur = new uint8_t[c]; w->cur_first = first; w->cur_count = c;
+                if (!w->dec) memcpy(w->cur, w->plane + first, c);
+                *count = c;
+                return w->cur;
+            }
+        };
+        for (size_t n : {(size_t)1, (size_t)60000, (size_t)60000 * 3, (size_t)60000 * 5 + 77}) {
+            const int count = 6;
+            std::vector<std::vector<uint8_t>> p(count), enc(count), wenc(count), back(count);
+            std::vector<Win> we(count), wd(count);
+            std::vector<wrrc::PlaneWindow> ioe(count), iod(count);
+            std::vector<const wrrc::PlaneWindow*> pe(count), pd(count);
+            std::vector<const uint8_t*> none(count, nullptr), ip(count);
+            std::vector<uint8_t*> op(count), noned(count, nullptr);
+            std::vector<size_t> len(count), wlen(count), got(count), ns(count, n);
+            for (int k = 0; k < count; k++) {
+                p[k].resize(n); back[k].assign(n, 0xEE);
+                for (size_t i = 0; i < n; i++) { unsigned r = rnd(); p[k][i] = k % 3 == 0 ? r & 255 : k % 3 == 1 ? ((r & 15) ? 254 : 255) : (uint8_t)(100 + (r & 31)); }
+                std::vector<uint8_t> o(wrrc::encode_bound(n));
+                len[k] = wrrc::encode_plane(p[k].data(), n, o.data(), nullptr);
+                enc[k].assign(o.begin(), o.begin() + len[k]);
+                wenc[k].resize(wrrc::encode_bound(n));
+                we[k] = Win{p[k].data(), nullptr, n, (size_t)60000 * (1 + k % 2), nullptr, 0, 0, false};
+                wd[k] = Win{nullptr, back[k].data(), n, (size_t)60000 * (1 + k % 2), nullptr, 0, 0, true};
+                ioe[k] = wrrc::PlaneWindow{Win::fn, &we[k]}; iod[k] = wrrc::PlaneWindow{Win::fn, &wd[k]};
+                pe[k] = &ioe[k]; pd[k] = &iod[k]; ip[k] = enc[k].data(); op[k] = wenc[k].data();
+            }
+            for (int mode = 0; mode < 2; mode++) {
+                if (mode == 0) wrrc::encode_planes(count, none.data(), n, op.data(), nullptr, wlen.data(), pe.data());
+                else if (!wrrc::encode_planes_vec(count, none.data(), ns.data(), op.data(), wlen.data(), pe.data())) continue;
+                for (int k = 0; k < count; k++) {
+                    delete[] we[k].cur; we[k].cur = nullptr;
+                    if (wlen[k] != len[k] || memcmp(wenc[k].data(), enc[k].data(), len[k])) { printf("windowed encode differs n=%zu mode=%d k=%d\n", n, mode, k); return 1; }
+                }
+                for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
+                if (mode == 0) wrrc::decode_planes(count, ip.data(), len.data(), noned.data(), n, got.data(), pd.data());
+                else wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data());
+                for (int k = 0; k < count; k++)
+                    if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("windowed decode failed n=%zu mode=%d k=%d\n", n, mode, k); return 1; }
+                // a truncated and a corrupted stream among healthy ones
+                for (int trial = 0; trial < 2 && n > 60000; trial++) {
+                    std::vector<uint8_t> bad(enc[1]);
+                    if (trial == 0) bad.resize(bad.size() / 2); else for (int j = 0; j < 16; j++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
+                    std::vector<const uint8_t*> ip2(ip); std::vector<size_t> l2(len);
+                    ip2[1] = bad.data(); l2[1] = bad.size();
+                    for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
+                    if (mode == 0) wrrc::decode_planes(count, ip2.data(), l2.data(), noned.data(), n, got.data(), pd.data());
+                    else wrrc::decode_planes_vec(count, ip2.data(), l2.data(), noned.data(), ns.data(), got.data(), pd.data());
+                    for (int k = 0; k < count; k++)
+                        if (k != 1 && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("windowed: healthy stream disturbed\n"); return 1; }
+                }
+            }
+        }
+    }
     printf("range coder sanitizer run OK\n");
     return 0;
 }

@@ -289,3 +289,43 @@ def test_avx512_decoder_loop_same_symbols(oracle):
             assert g == p.size and np.array_equal(d, p), ("pool", i, p.size)
     finally:
         api.set_coder_pool(0)
+
+
+@pytest.mark.parametrize("n", [1, 59999, 60000, 120000, 180001, 420000, 433333])
+def test_windowed_symbol_access_same_bytes_as_oracle(oracle, n):
+    """Planes that live in device memory reach the coder through windows of a pinned ring (wr_rangecoder.h,
+    PlaneWindow).  Here the windows are 1 or 2 blocks of plain host buffers (the one handed out before is poisoned):
+    streams and symbols must equal the oracle's on every loop -- scalar groups, the pool, the 16-lane loops --
+    for noise, dominant-symbol and constant planes, lengths at and around block and window boundaries (incl. the
+    empty trailing block of a plane that ends on a block boundary), and a corrupted stream next to healthy ones."""
+    from waverange_amd import api
+    rs = np.random.RandomState(n % 1000)
+    planes = [rs.randint(0, 256, n).astype(np.uint8),
+              rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.9, 0.1]),
+              np.where(rs.random_sample(n) < 0.999, 255, rs.randint(0, 256, n)).astype(np.uint8),
+              np.full(n, 7, np.uint8),
+              rs.randint(100, 140, n).astype(np.uint8)]
+    want = [oracle.range_encode(p) for p in planes]
+    api.set_coder_pool(3, 4)
+    try:
+        for chunk in (60000, 120000):
+            for mode in (0, 1, 2):
+                try:
+                    enc = api.range_encode_windowed(planes, chunk, mode)
+                    dec, got = api.range_decode_windowed(want, n, chunk, mode)
+                except api.WaveRangeError:
+                    assert mode == 2  # no AVX-512 on this CPU
+                    continue
+                for i, (a, b) in enumerate(zip(enc, want)):
+                    assert np.array_equal(a, b), ("encode", chunk, mode, i)
+                for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+                    assert g == n and np.array_equal(d, p), ("decode", chunk, mode, i)
+        if n > 100000:  # one damaged stream among healthy ones: the others are untouched, nothing crashes
+            bad = [w.copy() for w in want]
+            bad[0][len(bad[0]) // 2:] ^= 0x5A
+            for mode in (0, 1):
+                dec, got = api.range_decode_windowed(bad, n, 60000, mode)
+                for i in range(1, len(planes)):
+                    assert got[i] == n and np.array_equal(dec[i], planes[i]), ("healthy next to damaged", mode, i)
+    finally:
+        api.set_coder_pool(0)

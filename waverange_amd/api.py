@@ -133,6 +133,8 @@ def lib():
     L.wr_range_decode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_decode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_encode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
+    L.wr_range_encode_windowed.argtypes = [C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
+    L.wr_range_decode_windowed.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]
     L.wr_bench_transform.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     # drop-in symbols (reference src/core/wrappers.h:53,70,75)
     L.setup_wr.argtypes = [C.c_int] * 3 + [_u8p, _ulp]
@@ -205,6 +207,29 @@ def pinned_array(shape, dtype=np.float64):
     buf = (C.c_ubyte * owner.nbytes).from_address(owner.ptr)
     buf._owner = owner  # keeps the allocation alive as long as the ctypes buffer (numpy's base)
     return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
+def range_encode_windowed(planes, chunk, mode=0):
+    """Equally long planes coded through windows of `chunk` symbols (test hook of the device-resident plane path).
+    mode 0: interleaved loops on this thread, 1: the coder pool, 2: the 16-lane loops."""
+    ps = [np.ascontiguousarray(p, dtype=np.uint8).ravel() for p in planes]
+    k, n = len(ps), ps[0].size
+    assert all(p.size == n for p in ps)
+    outs = [np.empty(lib().wr_range_encode_bound(n), dtype=np.uint8) for _ in ps]
+    lens = (C.c_size_t * k)()
+    _check(lib().wr_range_encode_windowed(mode, k, (C.c_void_p * k)(*[p.ctypes.data for p in ps]), n, chunk,
+                                          (C.c_void_p * k)(*[o.ctypes.data for o in outs]), lens))
+    return [o[:lens[i]].copy() for i, o in enumerate(outs)]
+
+
+def range_decode_windowed(streams, n, chunk, mode=0):
+    ss = [np.ascontiguousarray(s, dtype=np.uint8).ravel() for s in streams]
+    k = len(ss)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for _ in ss]
+    got = (C.c_size_t * k)()
+    _check(lib().wr_range_decode_windowed(mode, k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
+                                          (C.c_void_p * k)(*[o.ctypes.data for o in outs]), n, chunk, got))
+    return [o[:n] for o in outs], [got[i] for i in range(k)]
 
 
 # ---------------------------------------------------------------------------------------

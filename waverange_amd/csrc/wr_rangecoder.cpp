@@ -255,6 +255,32 @@ inline void encode_block_header(Enc& e, const uint8_t* s, uint32_t bs, const uin
 constexpr int kMaxEncStreams = 3;
 
 namespace {
+// Where the symbols of a plane are: the whole plane in host memory, or the window of it that a PlaneWindow handed out.
+struct SymCursor {
+    uint8_t* base = nullptr;
+    size_t first = 0, count = 0;  // extent of what `base` points at
+    const PlaneWindow* io = nullptr;
+    void set(const uint8_t* whole, size_t n, const PlaneWindow* w)
+    {
+        io = w; first = 0;
+        if (w) { base = nullptr; count = 0; } else { base = const_cast<uint8_t*>(whole); count = n; }
+    }
+    // symbol `pos` of a plane of n symbols; moves the window on when pos has run out of it
+    uint8_t* at(size_t pos, size_t n)
+    {
+        if (io && pos >= first + count && pos < n) {
+            size_t c = n - pos;
+            base = io->window(io->user, pos, &c);
+            first = pos; count = c;
+        }
+        return base + (pos - first);
+    }
+    size_t room(size_t pos) const { return pos < first + count ? first + count - pos : 0; }  // symbols from pos on that exist here
+    void end(size_t pos) { if (io) { size_t z = 0; (void)io->window(io->user, pos, &z); } }
+};
+}  // namespace
+
+namespace {
 
 // A set of up to kMaxEncStreams plane streams that advance block by block in lockstep on one thread
 // (block loop of wrappers.cpp:85-128: a full final block is followed by an empty one).  Streams may join at
@@ -263,16 +289,17 @@ namespace {
 class EncGroup {
 public:
     struct Stream {
-        const uint8_t* sym; size_t n, done, blk; const uint16_t* hist;
+        SymCursor sym; size_t n, done, blk; const uint16_t* hist;
         void* tag;
     };
     int count() const { return count_; }
     bool full() const { return count_ == kMaxEncStreams; }
-    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag)
+    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag, const PlaneWindow* io = nullptr)
     {
         const int k = count_++;
         es_[k] = new (store_[k]) Enc(out);
-        st_[k] = Stream{sym, n, 0, 0, hist, tag};
+        st_[k] = Stream{SymCursor(), n, 0, 0, hist, tag};
+        st_[k].sym.set(sym, n, io);
     }
     // one block of every stream; on_end(tag, stream length) for the streams that ended with it
     template <class OnEnd>
@@ -284,7 +311,7 @@ public:
             Stream& s = st_[k];
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
-            ss_[k] = s.sym + s.done;
+            ss_[k] = s.sym.at(s.done, s.n);
             encode_block_header(*es_[k], ss_[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
             all_full = all_full && bs[k] == kBlock;
             topsel = topsel || (uint64_t)tabs_[k][tops_[k]].sy * 50 > bs[k];
@@ -340,11 +367,12 @@ public:
     VecEncGroup() { memset(tabs_, 0, sizeof tabs_); }
     int count() const { return count_; }
     bool full() const { return count_ == kCap; }
-    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag)
+    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag, const PlaneWindow* io = nullptr)
     {
         const int k = count_++;
         es_[k] = new (store_[k]) Enc(out);
-        st_[k] = EncGroup::Stream{sym, n, 0, 0, hist, tag};
+        st_[k] = EncGroup::Stream{SymCursor(), n, 0, 0, hist, tag};
+        st_[k].sym.set(sym, n, io);
     }
     template <class OnEnd>
     void step(OnEnd on_end)
@@ -357,7 +385,7 @@ public:
             EncGroup::Stream& s = st_[k];
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
-            const uint8_t* ss = s.sym + s.done;
+            const uint8_t* ss = s.sym.at(s.done, s.n);
             encode_block_header(*es_[k], ss, bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
             // the four most frequent symbols of the block; the vector loop takes the block if they hold >= 99 % of it
             uint32_t cand[kVecCand], covered = 0;
@@ -425,14 +453,15 @@ private:
 
 // `count` planes (any lengths, any statistics) on the calling thread through the 16-lane encoder loop: test and
 // measurement hook; the coder pool is the product path.  False if the CPU lacks AVX-512.
-bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, uint8_t* const* out, size_t* lens)
+bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, uint8_t* const* out, size_t* lens,
+                       const PlaneWindow* const* io)
 {
     if (!vec_available()) return false;
     std::unique_ptr<VecEncGroup> g(new VecEncGroup);
     int next = 0;
     while (next < count || g->count()) {
         while (next < count && !g->full()) {
-            g->add(sym[next], n[next], out[next], nullptr, lens + next);
+            g->add(sym[next], n[next], out[next], nullptr, lens + next, io ? io[next] : nullptr);
             next++;
         }
         g->step([](void* tag, size_t len) { *static_cast<size_t*>(tag) = len; });
@@ -440,14 +469,15 @@ bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, ui
     return true;
 }
 
-void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens)
+void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens,
+                   const PlaneWindow* const* io)
 {
     // up to kMaxEncStreams planes at a time in one symbol loop; further planes join as earlier ones end
     EncGroup g;
     int next = 0;
     while (next < count || g.count()) {
         while (next < count && !g.full()) {
-            g.add(sym[next], n, out[next], (hists && hists[next]) ? hists[next] : nullptr, lens + next);
+            g.add(sym[next], n, out[next], (hists && hists[next]) ? hists[next] : nullptr, lens + next, io ? io[next] : nullptr);
             next++;
         }
         g.step([](void* tag, size_t len) { *static_cast<size_t*>(tag) = len; });
@@ -783,11 +813,11 @@ public:
     }
     int count() const { return count_; }
     bool full() const { return count_ == cap_; }
-    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag)
+    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag, const PlaneWindow* io = nullptr)
     {
         const int k = count_++;
         ds_[k] = new (store_[k]) Dec(in, len);
-        sym_[k] = sym; n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
+        cur_[k].set(sym, n, io); n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
         tails_[k].clear();
     }
     // one block of every stream; on_end(tag, symbols the stream held or (size_t)-1) for the streams that ended
@@ -818,7 +848,8 @@ public:
                 }
             }
             if (ended) { retire(k, on_end); continue; }
-            dst_[k] = sym_[k] + (produced_[k] < n_[k] ? produced_[k] : n_[k]);
+            const size_t at = produced_[k] < n_[k] ? produced_[k] : n_[k];
+            dst_[k] = cur_[k].at(at, n_[k]);
             if (d.pos + kMargin > d.len && tails_[k].empty() && d.pos >= 1 && d.pos <= d.len) {
                 // near the end of the stream: continue on a zero-padded copy of the rest (reading past
                 // the end yields zeros, Dec::get), so that the unchecked loop stays usable
@@ -826,7 +857,7 @@ public:
                 memcpy(tails_[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
                 d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
             }
-            if (m.bs != kBlock || produced_[k] + kBlock > n_[k] || d.pos + kMargin > d.len) fast = false;
+            if (m.bs != kBlock || cur_[k].room(at) < kBlock || d.pos + kMargin > d.len) fast = false;
             k++;
         }
         if (!count_) return;
@@ -837,7 +868,7 @@ public:
         }
         for (int k = 0; k < count_;) {
             const BlockModel& m = *ms_[k];
-            const size_t room = produced_[k] < n_[k] ? n_[k] - produced_[k] : 0;
+            const size_t room = cur_[k].room(produced_[k] < n_[k] ? produced_[k] : n_[k]);  // symbols beyond it are dropped
             if (m.bs == kBlock) decode_symbols<kBlock>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
             else if (m.bs) decode_symbols<0>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
             produced_[k] += m.bs;
@@ -850,12 +881,13 @@ private:
     template <class OnEnd>
     void retire(int k, OnEnd on_end)
     {
+        cur_[k].end(produced_[k] < n_[k] ? produced_[k] : n_[k]);
         on_end(tag_[k], failed_[k] ? (size_t)-1 : produced_[k]);
         const int last = --count_;
         if (k != last) {  // the last slot moves into the hole
             ds_[k] = new (store_[k]) Dec(*ds_[last]);
             std::swap(ms_[k], ms_[last]);
-            sym_[k] = sym_[last]; n_[k] = n_[last]; produced_[k] = produced_[last]; failed_[k] = failed_[last]; tag_[k] = tag_[last];
+            cur_[k] = cur_[last]; n_[k] = n_[last]; produced_[k] = produced_[last]; failed_[k] = failed_[last]; tag_[k] = tag_[last];
             dst_[k] = dst_[last];
             // Dec may point into its tail copy: the vector's buffer moves with it
             tails_[k].swap(tails_[last]);
@@ -868,7 +900,7 @@ private:
     BlockModel* ms_[kMaxDecStreams];
     Dec* ds_[kMaxDecStreams];
     alignas(Dec) unsigned char store_[kMaxDecStreams][sizeof(Dec)];
-    uint8_t* sym_[kMaxDecStreams];
+    SymCursor cur_[kMaxDecStreams];
     uint8_t* dst_[kMaxDecStreams];
     size_t n_[kMaxDecStreams], produced_[kMaxDecStreams];
     bool failed_[kMaxDecStreams];
@@ -902,11 +934,11 @@ public:
     VecDecGroup() : models_((size_t)kCap) { for (int k = 0; k < kCap; k++) ms_[k] = &models_[k]; }
     int count() const { return count_; }
     bool full() const { return count_ == kCap; }
-    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag)
+    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag, const PlaneWindow* io = nullptr)
     {
         const int k = count_++;
         ds_[k] = new (store_[k]) Dec(in, len);
-        sym_[k] = sym; n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
+        cur_[k].set(sym, n, io); n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
         tails_[k].clear();
     }
     template <class OnEnd>
@@ -933,13 +965,14 @@ public:
                 else { m.top = top_sym; m.bs = bs; finish_model_stats(m); }
             }
             if (ended) { retire(k, on_end); continue; }
-            dst_[k] = sym_[k] + (produced_[k] < n_[k] ? produced_[k] : n_[k]);
+            const size_t at = produced_[k] < n_[k] ? produced_[k] : n_[k];
+            dst_[k] = cur_[k].at(at, n_[k]);
             if (d.pos + kMargin > d.len && tails_[k].empty() && d.pos >= 1 && d.pos <= d.len) {
                 tails_[k].assign(d.len - (d.pos - 1) + kMargin, 0);
                 memcpy(tails_[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
                 d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
             }
-            const bool fast = m.bs == kBlock && produced_[k] + kBlock <= n_[k] && d.pos + kMargin <= d.len;
+            const bool fast = m.bs == kBlock && cur_[k].room(at) >= kBlock && d.pos + kMargin <= d.len;
             vec[k] = fast && m.cand_ok;
             k++;
         }
@@ -973,7 +1006,7 @@ public:
             if (vec[k]) { k++; continue; }
             BlockModel& m = *ms_[k];
             if (!m.tables_ready) finish_model_tables(m);
-            const size_t room = produced_[k] < n_[k] ? n_[k] - produced_[k] : 0;
+            const size_t room = cur_[k].room(produced_[k] < n_[k] ? produced_[k] : n_[k]);
             if (m.bs == kBlock) decode_symbols<kBlock>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
             else if (m.bs) decode_symbols<0>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
             produced_[k] += m.bs;
@@ -992,12 +1025,13 @@ private:
     template <class OnEnd>
     void retire(int k, OnEnd on_end)
     {
+        cur_[k].end(produced_[k] < n_[k] ? produced_[k] : n_[k]);
         on_end(tag_[k], failed_[k] ? (size_t)-1 : produced_[k]);
         const int last = --count_;
         if (k != last) {
             ds_[k] = new (store_[k]) Dec(*ds_[last]);
             std::swap(ms_[k], ms_[last]);
-            sym_[k] = sym_[last]; n_[k] = n_[last]; produced_[k] = produced_[last]; failed_[k] = failed_[last]; tag_[k] = tag_[last];
+            cur_[k] = cur_[last]; n_[k] = n_[last]; produced_[k] = produced_[last]; failed_[k] = failed_[last]; tag_[k] = tag_[last];
             dst_[k] = dst_[last];
             tails_[k].swap(tails_[last]);
         }
@@ -1009,7 +1043,7 @@ private:
     BlockModel* ms_[kCap];
     Dec* ds_[kCap];
     alignas(Dec) unsigned char store_[kCap][sizeof(Dec)];
-    uint8_t* sym_[kCap];
+    SymCursor cur_[kCap];
     uint8_t* dst_[kCap];
     size_t n_[kCap], produced_[kCap];
     bool failed_[kCap];
@@ -1021,7 +1055,8 @@ private:
 
 // `count` streams of dominant-symbol planes (any lengths) on the calling thread through the 16-lane loop: test
 // and measurement hook; the coder pool is the product path.  False if the CPU lacks AVX-512.
-bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced)
+bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced,
+                       const PlaneWindow* const* io)
 {
     if (!vec_available()) return false;
     std::unique_ptr<VecDecGroup> g(new VecDecGroup);
@@ -1029,7 +1064,7 @@ bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, u
     while (next < count || g->count()) {
         while (next < count && !g->full()) {
             produced[next] = 0;
-            g->add(in[next], len[next], sym[next], n[next], produced + next);
+            g->add(in[next], len[next], sym[next], n[next], produced + next, io ? io[next] : nullptr);
             next++;
         }
         g->step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
@@ -1037,7 +1072,8 @@ bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, u
     return true;
 }
 
-void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced)
+void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced,
+                   const PlaneWindow* const* io)
 {
     // up to kMaxStreams planes at a time in one symbol loop; further planes join as earlier ones end
     DecGroup g(kMaxStreams);
@@ -1045,7 +1081,7 @@ void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8
     while (next < count || g.count()) {
         while (next < count && !g.full()) {
             produced[next] = 0;
-            g.add(in[next], len[next], sym[next], n, produced + next);
+            g.add(in[next], len[next], sym[next], n, produced + next, io ? io[next] : nullptr);
             next++;
         }
         g.step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
@@ -1072,6 +1108,7 @@ bool few_symbol_plane(const PlaneJob& j)
         const size_t blk = nblocks * (size_t)s / 8;
         uint32_t h[256];
         if (j.hist) for (int v = 0; v < 256; v++) h[v] = j.hist[blk * 256 + v];
+        else if (j.io) return false;  // a windowed plane without histograms: not sampled
         else histogram(j.src + blk * kBlock, kBlock, h);
         uint32_t top4[4] = {0, 0, 0, 0};
         for (int v = 0; v < 256; v++) {
@@ -1186,7 +1223,7 @@ private:
                     while (j) {
                         Tag* t = free_tag();
                         t->job = j; t->t0 = now_s();
-                        vg->add(j->src, j->src_len, j->dst, j->n, t);
+                        vg->add(j->src, j->src_len, j->dst, j->n, t, j->io);
                         j = vg->full() ? nullptr : pop(false, kVec);
                     }
                     vg->step(on_end);
@@ -1200,7 +1237,7 @@ private:
                     while (j) {
                         Tag* t = free_tag();
                         t->job = j; t->t0 = now_s();
-                        veg->add(j->src, j->n, j->dst, j->hist, t);
+                        veg->add(j->src, j->n, j->dst, j->hist, t, j->io);
                         j = veg->full() ? nullptr : pop(false, kVecEnc);
                     }
                     veg->step(on_end);
@@ -1214,7 +1251,7 @@ private:
                     while (j) {
                         Tag* t = free_tag();
                         t->job = j; t->t0 = now_s();
-                        dg->add(j->src, j->src_len, j->dst, j->n, t);
+                        dg->add(j->src, j->src_len, j->dst, j->n, t, j->io);
                         j = dg->full() ? nullptr : pop(false, kDec);
                     }
                     dg->step(on_end);
@@ -1225,7 +1262,7 @@ private:
                     while (j) {
                         Tag* t = free_tag();
                         t->job = j; t->t0 = now_s();
-                        eg.add(j->src, j->n, j->dst, j->hist, t);
+                        eg.add(j->src, j->n, j->dst, j->hist, t, j->io);
                         j = eg.full() ? nullptr : pop(false, kEnc);
                     }
                     eg.step(on_end);

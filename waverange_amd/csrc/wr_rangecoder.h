@@ -21,6 +21,17 @@ constexpr int kMaxDecStreams = 4;   // ... by a pool worker's decoder loop (5 an
 // upper bound on the stream length for n symbols
 size_t encode_bound(size_t n);
 
+// Windowed access to the symbol side of a plane that is not in host memory as a whole (it lives in device memory and
+// passes through a small pinned ring, wr_api.cpp).  `count` comes in as what is left of the plane from `first` on and
+// goes out as the length of the window handed back: a multiple of kBlock unless the plane ends in it.
+//   encoder: the symbols [first, first + count); the pointer stays valid until the next call.
+//   decoder: room for the symbols [first, first + count); the window handed out before is complete by then.  A call
+//            with *count == 0 ends the stream (the last window is complete; nothing is handed back).
+struct PlaneWindow {
+    uint8_t* (*window)(void* user, size_t first, size_t* count);
+    void* user;
+};
+
 // Encode n symbols; `out` must hold encode_bound(n) bytes.  `hists`, when non-null, holds
 // per-block byte histograms (uint16[256] per block, n/60000+1 blocks) computed on the GPU.
 // Returns the stream length.
@@ -29,7 +40,8 @@ size_t encode_plane(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* 
 // `count` planes of n symbols each on the calling thread, their symbol loops interleaved in
 // groups of up to kMaxStreams (same bytes as encode_plane on each).  hists may be null, and so
 // may its entries.
-void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens);
+void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens,
+                   const PlaneWindow* const* io = nullptr);  // io[k] non-null: plane k comes through windows, sym[k] is ignored
 
 // Decode a stream into exactly n symbols.  Returns the number of symbols the stream held
 // (== n for a well-formed stream; never writes more than n symbols, never reads past len).
@@ -37,15 +49,18 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n);
 
 // `count` streams of n symbols each on the calling thread, interleaved like encode_planes;
 // produced[k] as decode_plane's return value, (size_t)-1 for a stream that is not decodable.
-void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced);
+void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, size_t n, size_t* produced,
+                   const PlaneWindow* const* io = nullptr);  // io[k] non-null: plane k goes out through windows, sym[k] is ignored
 
 // `count` dominant-symbol planes (any lengths) on the calling thread, up to 16 at a time in the AVX-512 loop
 // (wr_rangecoder_vec.h); false if the CPU lacks AVX-512.  Same symbols as decode_plane on each.
-bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced);
+bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced,
+                       const PlaneWindow* const* io = nullptr);
 
 // `count` planes of any kind on the calling thread, up to 16 at a time in the AVX-512 encoder loop; false if the CPU
 // lacks AVX-512.  Same bytes as encode_plane on each.
-bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, uint8_t* const* out, size_t* lens);
+bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, uint8_t* const* out, size_t* lens,
+                       const PlaneWindow* const* io = nullptr);
 
 // ---- process-wide coder pool: plane streams of ALL concurrent encode / decode calls are coded by a fixed set
 // of worker threads.  A worker interleaves up to 3 encoder or up to `dec_streams` (<= kMaxDecStreams) decoder
@@ -64,6 +79,7 @@ struct PlaneJob {
     uint8_t* dst = nullptr;        // encode: encode_bound(n) bytes; decode: n symbols
     size_t n = 0;
     const uint16_t* hist = nullptr;  // encode: per-block histograms from the GPU, or null
+    const PlaneWindow* io = nullptr; // the symbol side (encode: src, decode: dst) comes / goes through windows instead
     size_t result = 0;             // encode: stream length; decode: symbols the stream held, (size_t)-1 if undecodable
     double seconds = 0;            // from the moment a worker took the job to its end
     JobBatch* batch = nullptr;
