@@ -169,14 +169,15 @@ int wr_set_device_slots(int device, int nslots);
 /* process-wide event counters (diagnostics and tests) */
 #define WR_STAT_EARLY_DECODES 0   /* decode calls that uploaded each plane as soon as it was decoded */
 #define WR_STAT_SLOTS_POPULATED 1 /* work-space slots that received device buffers */
-#define WR_STAT_STAGING_BYTES 2   /* host plane staging allocated right now (in use + idle), all devices */
+#define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
 unsigned long wr_stat(int what);
 
-/* One context per concurrent caller: (device, kernel stream, coded-stream buffers), grown on demand
- * and kept.  The device work space (wr_set_device_slots) and the pinned plane staging are shared
- * between the contexts of a GPU: a call borrows one staging buffer per plane while the plane is on
- * the host and returns it, so the staging held is that of the planes in flight, whatever the number
- * of contexts.  stream == NULL makes the context create its own. */
+/* One context per concurrent caller: (device, kernel stream, coded-stream buffers, and per plane a ring
+ * of two 15 MB pinned chunks), grown on demand and kept.  The device work space (wr_set_device_slots)
+ * and the device buffers of the quantized planes are shared between the contexts of a GPU: the planes
+ * stay in device memory -- a call borrows one buffer per plane while the plane exists and returns it
+ * -- and the host coder reads or writes them through the ring, chunk by chunk, so no whole plane is
+ * ever staged in host memory.  stream == NULL makes the context create its own. */
 int wr_ctx_create(wr_ctx **ctx, int device, void *hip_stream);
 void wr_ctx_destroy(wr_ctx *ctx);
 int wr_ctx_sync(wr_ctx *ctx);

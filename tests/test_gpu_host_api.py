@@ -41,7 +41,8 @@ def same_as_oracle(enc, want):
 
 @pytest.mark.parametrize("pinned", [True, False])
 @pytest.mark.parametrize("shape,tol,wtflag", [((64, 64, 64), 1e-7, 1), ((37, 21, 13), 1e-6, 1), ((128, 64, 80), 1e-4, 1),
-                                              ((64, 64, 8), 1e-4, 0), ((200, 120, 72), 1e-10, 1)])
+                                              ((64, 64, 8), 1e-4, 0), ((200, 120, 72), 1e-10, 1),
+                                              ((400, 300, 272), 1e-6, 1)])  # the last: planes of 2 windows + a partial one
 def test_host_entry_points_vs_oracle(ctx, api, oracle, pinned, shape, tol, wtflag):
     nx, ny, nz = shape
     f = synth.field(nx, ny, nz, seed=99)
@@ -85,10 +86,11 @@ def test_host_trivial_field_and_transform(ctx, api, oracle, golden):
 
 
 def test_plane_ordered_upload_under_the_decoder(ctx, api, oracle):
-    """with a coder thread per plane, every plane is uploaded the moment it is decoded while
-    later planes are still being decoded; the accumulate kernel consumes them in plane order.  The counter
-    proves that path ran; the reconstruction must equal the oracle's (the order of the sums matters,
-    wrappers.cpp:513-514)."""
+    """the decoded symbols go to the plane's device buffer window by window while the decoder is
+    still at work on the rest (and on the other planes); the accumulate kernel consumes the planes in plane order.
+    The counter proves that path ran; the reconstruction must equal the oracle's (the order of the sums matters,
+    wrappers.cpp:513-514).  180 x 190 x 200 symbols are less than one 15 MB window; the full-size tests cover
+    planes of 70 windows."""
     api.set_threads(8)
     f = synth.field(180, 190, 200, seed=21)
     for tol in (1e-7, 1e-16):
@@ -105,13 +107,13 @@ def test_plane_ordered_upload_under_the_decoder(ctx, api, oracle):
         assert api.stat(api.STAT_EARLY_DECODES) == before + 2
         assert bits_equal(buf.download(np.float64, f.size), rec)
         buf.free()
-    # grouped coder threads: the slot is claimed after the host decode (no early upload), same result
+    # grouped coder threads (planes interleaved in one loop): the same path, the same result
     api.set_threads(2)
     try:
         before = api.stat(api.STAT_EARLY_DECODES)
         out = np.empty_like(f)
         ctx.decode_host(out, want)
-        assert api.stat(api.STAT_EARLY_DECODES) == before
+        assert api.stat(api.STAT_EARLY_DECODES) == before + 1
         assert bits_equal(out, rec)
     finally:
         api.set_threads(8)
@@ -379,21 +381,36 @@ def test_two_phase_decode(ctx, api, oracle):
     assert np.array_equal(out, g)
 
 
-def test_plane_staging_is_shared_between_contexts(api, oracle):
-    """The pinned plane staging belongs to the device, not to the context: three contexts used one after the other
-    hold one set of buffers between them; planes parked by wr_decode_begin stay untouched while other contexts
-    borrow and return buffers, and go back to the pool after the finish."""
+def test_small_windows_on_every_path():
+    """The planes reach the host coder through 15 MB windows of a pinned ring; with WR_WINDOW_BLOCKS=1 a window is one
+    coder block (60000 symbols), so the small fields of the tests in this file and of the parity file cross dozens of
+    window boundaries on every path (thread per plane, grouped threads, the pool, two-call decodes, the drop-in
+    symbols): run them again in a child process with that setting."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = ("(codec or trivial or drop_in or local_cutoff or error_paths or concurrent_contexts or grouped_coder or random_shapes "
+           "or zero_minimum or host_entry_points or plane_ordered or coder_pool or two_phase or beyond_the_launch "
+           "or device_planes) and not (full_size or large_roundtrip or config4 or small_windows)")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_host_api.py"),
+                        os.path.join(here, "test_gpu_parity.py"), "-k", sel],
+                       env=dict(os.environ, WR_WINDOW_BLOCKS="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_device_planes_are_shared_between_contexts(api, oracle):
+    """The quantized planes live in device buffers that belong to the device, not to the context: three contexts used
+    one after the other hold one set of buffers between them; planes parked by wr_decode_begin stay untouched while
+    other contexts borrow and return buffers, and go back to the pool after the finish."""
     f = synth.field(96, 100, 104, seed=33)
     g = synth.field(96, 100, 104, seed=34)
     want_f, want_g = oracle.encode(f, 1e-7), oracle.encode(g, 1e-7)
     pitch = (f.size + 255) // 256 * 256
-    base = api.stat(api.STAT_STAGING_BYTES)
+    base = api.stat(api.STAT_DEVICE_PLANE_BYTES)
     ctxs = [api.Context(0) for _ in range(3)]
     try:
         for c in ctxs:
             enc, _ = c.encode_host(f.copy(), 1e-7)
             same_as_oracle(enc, want_f)
-        one_set = api.stat(api.STAT_STAGING_BYTES) - base
+        one_set = api.stat(api.STAT_DEVICE_PLANE_BYTES) - base
         assert one_set <= (want_f["nlay"] + 1) * pitch, one_set         # at most one new set (idle buffers of earlier tests fit too), not three
         ctxs[0].decode_begin(f.shape, want_f)                           # parks nlay planes in context 0
         for c in ctxs[1:]:                                              # the others borrow different buffers meanwhile
@@ -405,7 +422,7 @@ def test_plane_staging_is_shared_between_contexts(api, oracle):
         out = np.empty(f.shape)
         ctxs[0].decode_finish_host(out)
         assert bits_equal(out, oracle.decode(want_f, f.shape))
-        two_sets = api.stat(api.STAT_STAGING_BYTES) - base
+        two_sets = api.stat(api.STAT_DEVICE_PLANE_BYTES) - base
         assert two_sets <= 2 * (max(want_f["nlay"], want_g["nlay"]) + 1) * pitch, two_sets
     finally:
         for c in ctxs:

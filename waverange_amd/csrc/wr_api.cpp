@@ -114,14 +114,13 @@ struct Slot {
     double* field = nullptr; size_t field_elems = 0;      // staging of a host caller's field
     double* scratch = nullptr; size_t scratch_elems = 0;  // coefficient array (out-of-place fused transform)
     double* lowbuf = nullptr; size_t lowbuf_elems = 0;    // compact low-pass boxes (fused transform)
-    uint8_t* planes = nullptr; size_t planes_bytes = 0;   // quantized planes
     uint16_t* hist = nullptr; size_t hist_elems = 0;      // per-block byte histograms, all planes
-    bool allocated() const { return field || scratch || lowbuf || planes || hist; }
+    bool allocated() const { return field || scratch || lowbuf || hist; }
     void release_buffers()
     {
-        (void)hipFree(field); (void)hipFree(scratch); (void)hipFree(lowbuf); (void)hipFree(planes); (void)hipFree(hist);
-        field = scratch = lowbuf = nullptr; planes = nullptr; hist = nullptr;
-        field_elems = scratch_elems = lowbuf_elems = planes_bytes = hist_elems = 0;
+        (void)hipFree(field); (void)hipFree(scratch); (void)hipFree(lowbuf); (void)hipFree(hist);
+        field = scratch = lowbuf = nullptr; hist = nullptr;
+        field_elems = scratch_elems = lowbuf_elems = hist_elems = 0;
     }
 };
 
@@ -133,18 +132,19 @@ constexpr int kMaxSlots = 4;
 // field staging, coefficients and planes, 1.2 GB of low-pass boxes; slots are populated on demand, so a
 // lone caller uses one), one copy stream per direction (copies of all contexts queue on them in call
 // order and stay off the streams that run kernels) and the stage locks.
-// Pinned host staging of quantized planes, shared by the contexts of one device: a call borrows one buffer per
-// plane for as long as the plane lives on the host (encode: download -> coded; decode: decoded -> uploaded) and
-// hands it back, so 16 fields in flight hold the planes in flight, not 16 x (encode set + decode set).
-struct PlaneStaging {
-    struct Buf { uint8_t* p = nullptr; size_t bytes = 0; bool pinned = false; };
+// Quantized planes live in DEVICE memory, in buffers shared by the contexts of one device: a call borrows one per
+// plane for as long as the plane exists (encode: quantized until coded; decode: from the first decoded symbol until the
+// inverse transform has read it, parked in the context between wr_decode_begin and wr_decode_finish_*) and hands it
+// back.  The host coder sees a plane only through a ring of two pinned chunks (PlaneStream below), so 16 fields in
+// flight cost ~100 GiB of the 288 GB of HBM instead of that much pinned host memory.
+struct DevPlanes {
+    struct Buf { uint8_t* p = nullptr; size_t bytes = 0; };
     std::mutex mu;
     std::vector<Buf> idle;
-    static void release(const Buf& b) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
     void drop_idle()
     {
         std::lock_guard<std::mutex> lk(mu);
-        for (const Buf& b : idle) { g_stat[WR_STAT_STAGING_BYTES] -= b.bytes; release(b); }
+        for (const Buf& b : idle) { g_stat[WR_STAT_DEVICE_PLANE_BYTES] -= b.bytes; (void)hipFree(b.p); }
         idle.clear();
     }
     // smallest idle buffer that holds `bytes` without being more than twice as large, else a new one
@@ -158,21 +158,13 @@ struct PlaneStaging {
             if (best >= 0) { Buf b = idle[best]; idle[best] = idle.back(); idle.pop_back(); return b; }
         }
         Buf b;
-        b.bytes = bytes;
         void* q = nullptr;
-        if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
+        if (hipMalloc(&q, bytes) != hipSuccess) {
             (void)hipGetLastError();
-            drop_idle();  // buffers of another field size may be holding the pinned memory
-            if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+            drop_idle();  // buffers of another field size may be holding the memory
+            if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
         }
-        if (q) { b.p = static_cast<uint8_t*>(q); b.pinned = true; }
-        else {
-            // no pinned memory left (many contexts of many ranks on one host): pageable staging works,
-            // the copy is then staged by the runtime and slower
-            b.p = static_cast<uint8_t*>(aligned_alloc(4096, (bytes + 4095) / 4096 * 4096));
-            b.pinned = false;
-        }
-        if (b.p) g_stat[WR_STAT_STAGING_BYTES] += bytes;
+        if (q) { b.p = static_cast<uint8_t*>(q); b.bytes = bytes; g_stat[WR_STAT_DEVICE_PLANE_BYTES] += bytes; }
         return b;
     }
     void give(const Buf& b)
@@ -189,7 +181,7 @@ struct DevPool {
     int users = 0;
     hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
-    PlaneStaging staging;
+    DevPlanes planes;
 };
 
 struct wr_ctx {
@@ -205,8 +197,6 @@ struct wr_ctx {
     // pinned host
     double* h_result = nullptr;  // [0..1] min/max, [2] probe value, [3] index, [4..7] fused min/max
     double* h_result_dev = nullptr;  // the same block as the device sees it: reductions write their result straight to the host
-    uint8_t* h_plane[WR_NLAYMAX] = {nullptr}; size_t h_plane_bytes[WR_NLAYMAX] = {0};  // pinned, one per plane, on demand
-    bool h_plane_pinned[WR_NLAYMAX] = {false};
     uint16_t* h_hist = nullptr; size_t h_hist_elems = 0;  // pinned: per-block byte histograms, all planes
     // host coded-stream staging, one per plane
     uint8_t* enc_buf[WR_NLAYMAX] = {nullptr}; size_t enc_buf_bytes[WR_NLAYMAX] = {0};  // malloc'd: only coded bytes get touched
@@ -221,8 +211,24 @@ struct wr_ctx {
         double t_start = 0, ms = 0;  // duration: engine timestamps of the last DMA copy, else host clock
         std::mutex mu;               // several threads may wait for the same transfer
     };
-    Xfer x_field, x_plane[WR_NLAYMAX];
-    // two-phase decode (wr_decode_begin / wr_decode_finish_*): the planes are decoded and wait in h_plane
+    Xfer x_field, x_plane[WR_NLAYMAX];  // x_plane: the block histograms of an encode's plane
+    // A quantized plane of this context: in device memory (borrowed from DevPool::planes), and the ring of two pinned
+    // chunks through which the host coder reads (encode) or writes (decode) it, window by window (wrrc::PlaneWindow)
+    struct PlaneStream {
+        wr_ctx* c = nullptr;
+        uint8_t* dev = nullptr; size_t dev_bytes = 0;
+        size_t n = 0;
+        uint8_t* buf[2] = {nullptr, nullptr};  // pinned, kChunkSyms + 64 bytes each; allocated at first use, kept
+        Xfer x[2];
+        int cur = 1;                            // buffer of the window handed out last
+        size_t win_first = 0, win_count = 0;    // decode: the window being filled
+        bool ahead = false; size_t ahead_first = 0;  // encode: the chunk in flight into buf[cur ^ 1]
+        int err = 0;
+        double copy_ms = 0;
+        wrrc::PlaneWindow io;
+    };
+    PlaneStream ps[WR_NLAYMAX];
+    // two-phase decode (wr_decode_begin / wr_decode_finish_*): the planes are decoded and wait in ps[].dev
     bool pend_valid = false;
     wr_enc_info pend_info;
     int pend_nx = 0, pend_ny = 0, pend_nz = 0;
@@ -240,7 +246,7 @@ std::mutex g_pools_mu;
 
 // what a phase needs from its slot (0 = not needed)
 struct SlotNeed {
-    size_t field_elems = 0, scratch_elems = 0, lowbuf_elems = 0, planes_bytes = 0, hist_elems = 0;
+    size_t field_elems = 0, scratch_elems = 0, lowbuf_elems = 0, hist_elems = 0;
 };
 
 template <class T>
@@ -260,7 +266,6 @@ hipError_t slot_ensure(Slot* s, const SlotNeed& need)
     if ((e = grow(&s->field, &s->field_elems, need.field_elems)) != hipSuccess) return e;
     if ((e = grow(&s->scratch, &s->scratch_elems, need.scratch_elems)) != hipSuccess) return e;
     if ((e = grow(&s->lowbuf, &s->lowbuf_elems, need.lowbuf_elems)) != hipSuccess) return e;
-    if ((e = grow(&s->planes, &s->planes_bytes, need.planes_bytes)) != hipSuccess) return e;
     if ((e = grow(&s->hist, &s->hist_elems, need.hist_elems)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -332,36 +337,6 @@ private:
 };
 
 using StageLock = std::unique_lock<std::mutex>;
-
-// pinned staging of plane l, borrowed from the device's pool the moment a field needs that plane (a 1024^3
-// field at tol 1e-3 borrows 3 GiB here, not 8) and handed back by the HostPlanes guard of the call
-void release_host_plane(wr_ctx* c, int l)
-{
-    if (!c->h_plane[l]) return;
-    PlaneStaging::Buf b; b.p = c->h_plane[l]; b.bytes = c->h_plane_bytes[l]; b.pinned = c->h_plane_pinned[l];
-    c->pool->staging.give(b);
-    c->h_plane[l] = nullptr; c->h_plane_bytes[l] = 0;
-}
-
-int ensure_host_plane(wr_ctx* c, int l, size_t bytes)
-{
-    if (c->h_plane[l] && c->h_plane_bytes[l] >= bytes) return WR_OK;
-    release_host_plane(c, l);
-    const PlaneStaging::Buf b = c->pool->staging.take(bytes);
-    if (!b.p) return fail(WR_ERR_ARG, "out of host memory for the plane staging buffer");
-    c->h_plane[l] = b.p; c->h_plane_bytes[l] = b.bytes; c->h_plane_pinned[l] = b.pinned;
-    return WR_OK;
-}
-
-// Declared before anything that may still touch the staging when the call unwinds (coder threads, transfers
-// are all waited for by then): returns the context's planes to the pool unless the call parks them
-// (wr_decode_begin keeps the decoded planes for wr_decode_finish_*).
-struct HostPlanes {
-    wr_ctx* c;
-    bool keep = false;
-    explicit HostPlanes(wr_ctx* ctx) : c(ctx) {}
-    ~HostPlanes() { if (!keep) for (int l = 0; l < WR_NLAYMAX; l++) release_host_plane(c, l); }
-};
 
 int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
 {
@@ -447,6 +422,148 @@ int xfer_wait(wr_ctx::Xfer* x)
         x->ms = (now() - x->t_start) * 1e3;
     }
     return rc;
+}
+
+// ---- device-resident planes and their host windows -------------------------------------------------------------------
+// a window: 256 coder blocks, 15.36 MB, ~0.3 ms on a DMA engine (WR_WINDOW_BLOCKS: 1..256 blocks, for tests that want
+// many windows on small fields)
+const size_t kChunkSyms = []() {
+    int blocks = 256;
+    if (const char* e = getenv("WR_WINDOW_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 256) blocks = v; }
+    return (size_t)blocks * wrrc::kBlock;
+}();
+const size_t kChunkBytes = 256 * (size_t)wrrc::kBlock + 64;  // ring buffers are always full-size
+
+using PlaneStream = wr_ctx::PlaneStream;
+
+void plane_release(wr_ctx* c, int l)
+{
+    PlaneStream& s = c->ps[l];
+    if (!s.dev) return;
+    DevPlanes::Buf b; b.p = s.dev; b.bytes = s.dev_bytes;
+    c->pool->planes.give(b);
+    s.dev = nullptr; s.dev_bytes = 0;
+}
+
+// Encoder side: the symbols [first, first + count) of the plane, fetched into the ring; the following chunk is
+// started into the buffer the coder has just left, so that it arrives while this one is being coded.
+uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
+{
+    PlaneStream& s = *static_cast<PlaneStream*>(user);
+    wr_ctx* const c = s.c;
+    (void)hipSetDevice(c->device);  // coder threads: the pageable-copy fallback of xfer_start needs the device bound
+    const size_t want = *count < kChunkSyms ? *count : kChunkSyms;
+    const int b = s.cur ^ 1;
+    if (!(s.ahead && s.ahead_first == first)) {
+        if (s.ahead) (void)xfer_wait(&s.x[b]);
+        const Piece pc = {s.buf[b], s.dev + first, want};
+        if (xfer_start(c, &s.x[b], &pc, 1, kDown) != WR_OK) s.err = 1;
+    }
+    if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;
+    s.copy_ms += s.x[b].ms;
+    s.cur = b;
+    s.ahead = false;
+    const size_t next = first + want;
+    if (next < s.n) {
+        const Piece pc = {s.buf[b ^ 1], s.dev + next, s.n - next < kChunkSyms ? s.n - next : kChunkSyms};
+        if (xfer_start(c, &s.x[b ^ 1], &pc, 1, kDown) == WR_OK) { s.ahead = true; s.ahead_first = next; }
+        else s.err = 1;
+    }
+    *count = want;
+    return s.buf[b];
+}
+
+// Decoder side: room for the symbols from `first` on; the window handed out before goes to the device meanwhile.
+// *count == 0 ends the stream: both uploads are waited for.
+uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
+{
+    PlaneStream& s = *static_cast<PlaneStream*>(user);
+    wr_ctx* const c = s.c;
+    (void)hipSetDevice(c->device);
+    if (s.win_count) {
+        const Piece pc = {s.dev + s.win_first, s.buf[s.cur], s.win_count};
+        if (xfer_start(c, &s.x[s.cur], &pc, 1, kUp) != WR_OK) s.err = 1;
+        s.win_count = 0;
+    }
+    if (*count == 0) {
+        for (int b = 0; b < 2; b++) { if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1; s.copy_ms += s.x[b].ms; s.x[b].ms = 0; }
+        return nullptr;
+    }
+    const int b = s.cur ^ 1;
+    if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;  // the upload of two windows ago
+    s.copy_ms += s.x[b].ms; s.x[b].ms = 0;
+    s.cur = b;
+    s.win_first = first;
+    s.win_count = *count < kChunkSyms ? *count : kChunkSyms;
+    *count = s.win_count;
+    return s.buf[b];
+}
+
+// plane l of n symbols for this call: a device buffer (kept if the context holds one that fits: a finish after a
+// begin), the ring, and the window callbacks of the direction
+int plane_prepare(wr_ctx* c, int l, size_t n, bool decode)
+{
+    PlaneStream& s = c->ps[l];
+    const size_t bytes = wr_plane_pitch(n);
+    if (!s.dev || s.dev_bytes < bytes) {
+        plane_release(c, l);
+        const DevPlanes::Buf b = c->pool->planes.take(bytes);
+        if (!b.p) return fail(WR_ERR_HIP, "out of device memory for a quantized plane (fewer calls in flight need less)");
+        s.dev = b.p; s.dev_bytes = b.bytes;
+    }
+    for (int b = 0; b < 2; b++)
+        if (!s.buf[b]) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s.buf[b]), kChunkBytes, hipHostMallocDefault));
+    s.c = c; s.n = n;
+    s.cur = 1; s.win_first = s.win_count = 0; s.ahead = false; s.ahead_first = 0; s.err = 0; s.copy_ms = 0;
+    s.x[0].ms = s.x[1].ms = 0;
+    s.io.window = decode ? plane_window_decode : plane_window_encode;
+    s.io.user = &s;
+    return WR_OK;
+}
+
+// encode: the plane is complete on the device -- its first chunk sets off for the host before a coder asks for it
+void plane_prefetch(wr_ctx* c, int l)
+{
+    PlaneStream& s = c->ps[l];
+    if (!s.n) return;
+    const Piece pc = {s.buf[s.cur ^ 1], s.dev, s.n < kChunkSyms ? s.n : kChunkSyms};
+    if (xfer_start(c, &s.x[s.cur ^ 1], &pc, 1, kDown) == WR_OK) { s.ahead = true; s.ahead_first = 0; }
+    else s.err = 1;
+}
+
+// Declared before anything that may still touch the planes when the call unwinds (coder threads are joined, pool
+// jobs waited for by then): hands the context's device planes back unless the call parks them (wr_decode_begin keeps
+// the decoded planes for wr_decode_finish_*).
+struct PlaneHold {
+    wr_ctx* c;
+    bool keep = false;
+    explicit PlaneHold(wr_ctx* ctx) : c(ctx) {}
+    ~PlaneHold()
+    {
+        if (keep) return;
+        for (int l = 0; l < WR_NLAYMAX; l++) {
+            PlaneStream& s = c->ps[l];
+            if (s.dev) { (void)xfer_wait(&s.x[0]); (void)xfer_wait(&s.x[1]); }  // a prefetch nobody consumed (error paths)
+            s.ahead = false;
+            plane_release(c, l);
+        }
+    }
+};
+
+// a whole plane on the host, for the diagnostics of the verbose mode (wrappers.cpp:401-409, 503-510)
+std::string plane_log(wr_ctx* c, int l, size_t n, const wr_enc_info* info, bool encode, size_t len)
+{
+    std::vector<uint8_t> q(n);
+    if (hipMemcpy(q.data(), c->ps[l].dev, n, hipMemcpyDeviceToHost) != hipSuccess) return std::string();
+    unsigned lo = q[0], hi = q[0];
+    for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    char b[256];
+    if (encode)
+        snprintf(b, sizeof b, "imin=%u imax=%u med=%g\nlen_out_q=%lu ntot=%lu\n", lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l],
+                 (unsigned long)len, (unsigned long)n);
+    else
+        snprintf(b, sizeof b, "ilay=%d\nimin=%u imax=%u med=%g\n", l, lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l]);
+    return b;
 }
 
 bool use_fused(int nx, int ny, int nz, int lvl)
@@ -650,8 +767,9 @@ static int ctx_init(wr_ctx* c, int device, void* hip_stream)
     HIPCHK(hipEventCreate(&c->ev_a)); HIPCHK(hipEventCreate(&c->ev_b));
     HIPCHK(hipEventCreate(&c->ev_c)); HIPCHK(hipEventCreate(&c->ev_d));
     HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
-    for (wr_ctx::Xfer* x : {&c->x_field, &c->x_plane[0], &c->x_plane[1], &c->x_plane[2], &c->x_plane[3], &c->x_plane[4],
-                            &c->x_plane[5], &c->x_plane[6], &c->x_plane[7]}) {
+    std::vector<wr_ctx::Xfer*> xs = {&c->x_field};
+    for (int l = 0; l < WR_NLAYMAX; l++) { xs.push_back(&c->x_plane[l]); xs.push_back(&c->ps[l].x[0]); xs.push_back(&c->ps[l].x[1]); }
+    for (wr_ctx::Xfer* x : xs) {
         x->sig = wrdma::signal_create();  // 0 if ROCr is not usable: every copy then goes through hipMemcpyAsync
         HIPCHK(hipEventCreateWithFlags(&x->ev, hipEventDisableTiming));
     }
@@ -694,7 +812,9 @@ void wr_ctx_destroy(wr_ctx* c)
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_hist) (void)hipHostFree(c->h_hist);
     for (int l = 0; l < WR_NLAYMAX; l++) {
-        release_host_plane(c, l);
+        (void)xfer_wait(&c->ps[l].x[0]); (void)xfer_wait(&c->ps[l].x[1]);
+        plane_release(c, l);
+        for (uint8_t* b : c->ps[l].buf) if (b) (void)hipHostFree(b);
         free(c->enc_buf[l]);
     }
     for (int i = 0; i < WR_NLAYMAX; i++) {
@@ -702,8 +822,9 @@ void wr_ctx_destroy(wr_ctx* c)
     }
     for (hipEvent_t ev : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_mm})
         if (ev) (void)hipEventDestroy(ev);
-    for (wr_ctx::Xfer* x : {&c->x_field, &c->x_plane[0], &c->x_plane[1], &c->x_plane[2], &c->x_plane[3], &c->x_plane[4],
-                            &c->x_plane[5], &c->x_plane[6], &c->x_plane[7]}) {
+    std::vector<wr_ctx::Xfer*> xs = {&c->x_field};
+    for (int l = 0; l < WR_NLAYMAX; l++) { xs.push_back(&c->x_plane[l]); xs.push_back(&c->ps[l].x[0]); xs.push_back(&c->ps[l].x[1]); }
+    for (wr_ctx::Xfer* x : xs) {
         wrdma::signal_destroy(x->sig);
         if (x->ev) (void)hipEventDestroy(x->ev);
     }
@@ -716,7 +837,7 @@ void wr_ctx_destroy(wr_ctx* c)
             if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); p->up = nullptr; }
             if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); p->down = nullptr; }
             for (Slot& s : p->slots) s.release_buffers();
-            p->staging.drop_idle();
+            p->planes.drop_idle();
         }
     }
     delete c;
@@ -893,9 +1014,9 @@ struct Cutoff {
 // plane's min/max have been enqueued (the block histograms are enqueued there, behind the read-back);
 // plane_ready(l, last) is called from the host once everything enqueued for plane l has completed on the
 // device (the download starts there).  *resid = where the coefficient array / residual lives afterwards.
-template <class AfterQuant, class PlaneReady>
+template <class PlaneBuf, class AfterQuant, class PlaneReady>
 int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
-                       uint8_t* d_planes, wr_enc_info* info, wr_timings* tm, AfterQuant after_quant, PlaneReady plane_ready,
+                       PlaneBuf plane_buf, wr_enc_info* info, wr_timings* tm, AfterQuant after_quant, PlaneReady plane_ready,
                        double** resid)
 {
     // minimum cutoff = the global relative tolerance (wrappers.cpp:288-290)
@@ -912,7 +1033,6 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         HIPCHK(hipMemcpyAsync(c->d_cutoff, cut.vec, cut.count() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     const size_t n = (size_t)nx * ny * nz;
-    const size_t pitch = wr_plane_pitch(n);
     Prologue p;
     *resid = d_fld;
     double lo, hi;
@@ -989,6 +1109,8 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         info->deps_vec[ilay] = s.deps;
         if (verbose()) { printf("min=%g max=%g\n", lo, hi); printf("ilay=%u deps=%g\n", ilay, s.deps); }
         const bool resid_upd = !s.last || c->keep_residual;
+        uint8_t* const d_plane = plane_buf(ilay);  // device memory of this plane (the error is set if there is none)
+        if (!d_plane) return WR_ERR_HIP;
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
         if (local) {
             wrk::LocalCutoff lc;
@@ -998,10 +1120,10 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
             lc.tol_scale = info->tolabs / tolrel;
             lc.tolabs = info->tolabs;
             lc.span = hi - lo;
-            wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, lc,
+            wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_plane, lc,
                                       c->d_partial, c->h_result_dev, c->stream);
         } else
-        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_planes + ilay * pitch, resid_upd,
+        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_plane, resid_upd,
                             c->d_partial, c->h_result_dev, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
         HIPCHK(hipGetLastError());
@@ -1048,7 +1170,8 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     StageLock cu(c->pool->cu_mu);
     Cutoff cut; cut.vec = &tolrel;
     double* resid = nullptr;
-    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, d_planes, info, nullptr,
+    const size_t pitch = wr_plane_pitch((size_t)nx * ny * nz);
+    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, [&](unsigned l) { return d_planes + l * pitch; }, info, nullptr,
                                 [](unsigned) { return WR_OK; }, [](unsigned, bool) { return WR_OK; }, &resid);
     if (rc == WR_OK && resid != d_fld && info->nlay)  // d_fld holds the residual afterwards (header contract)
         if (hipMemcpyAsync(d_fld, resid, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
@@ -1109,7 +1232,6 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     std::lock_guard<std::mutex> lk(c->mu);
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
-    const size_t pitch = wr_plane_pitch(n);
     wr_timings local; memset(&local, 0, sizeof local);
     // per-60000-symbol-block byte histograms, counted on the GPU next to the quantizer and shipped
     // with the plane, so that the host coder starts every block with its model ready
@@ -1122,11 +1244,13 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     std::string logs[WR_NLAYMAX];
     Sem sem(encoder_threads());
     const int dev = c->device;
-    HostPlanes staging(c);  // before the workers: they are joined first when the call unwinds
+    c->pend_valid = false;  // planes a wr_decode_begin parked in this context do not survive an encode on it
+    PlaneHold planes(c);  // before the workers: they are joined first when the call unwinds
     Workers workers;
 
-    // With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
-    // on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
+    // The planes stay in device memory; a coder reads its plane through the plane's ring of pinned chunks
+    // (PlaneStream).  With a coder thread for every possible plane, plane l's thread starts as soon as the plane is
+    // complete on the device and its histograms are on the host.  With fewer (wr_set_threads), the planes are split into that many groups once
     // their number is known and each thread codes its group with the symbol loops interleaved.
     const bool pooled = wrrc::pool_threads() > 0;  // the process-wide coder pool codes the planes (wr_set_coder_pool)
     const bool per_plane = !pooled && encoder_threads() >= WR_NLAYMAX;
@@ -1142,26 +1266,16 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         const uint8_t* syms[WR_NLAYMAX];
         uint8_t* outs[WR_NLAYMAX];
         const uint16_t* hs[WR_NLAYMAX];
-        for (unsigned l = l0; l < l1; l++) { syms[l - l0] = c->h_plane[l]; outs[l - l0] = c->enc_buf[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; }
-        wrrc::encode_planes((int)(l1 - l0), syms, n, outs, hs, lens + l0);
+        const wrrc::PlaneWindow* ios[WR_NLAYMAX];
+        for (unsigned l = l0; l < l1; l++) { syms[l - l0] = nullptr; outs[l - l0] = c->enc_buf[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; ios[l - l0] = &c->ps[l].io; }
+        wrrc::encode_planes((int)(l1 - l0), syms, n, outs, hs, lens + l0, ios);
         for (unsigned l = l0; l < l1; l++) coder_s[l] = now() - t;
         sem.release();
-        if (verbose())  // wrappers.cpp:401-409, 430
-            for (unsigned l = l0; l < l1; l++) {
-                const uint8_t* q = c->h_plane[l];
-                unsigned lo = q[0], hi = q[0];
-                for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-                char b[256];
-                snprintf(b, sizeof b, "imin=%u imax=%u med=%g\nlen_out_q=%lu ntot=%lu\n", lo, hi,
-                         q[n / 2] * info->deps_vec[l] + info->minval_vec[l], (unsigned long)lens[l], (unsigned long)n);
-                logs[l] = b;
-            }
     };
 
     SlotNeed need;
     transform_need(nx, ny, nz, wtflag ? kWavLvl : 0, &need);
     if (fld.host) need.field_elems = n;
-    need.planes_bytes = pitch * WR_NLAYMAX;
     need.hist_elems = hist_per_plane * WR_NLAYMAX;
     if (int rc = ensure_host_hist(c, hist_per_plane * WR_NLAYMAX)) return rc;
 
@@ -1185,17 +1299,17 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         double* resid = d_fld;
         auto after_quant = [&](unsigned l) -> int {
             // block histograms of plane l on the kernel stream, behind the read-back of the next plane's min/max
-            wrk::block_histograms(slot->planes + l * pitch, n, slot->hist + l * hist_per_plane, c->stream);
+            wrk::block_histograms(c->ps[l].dev, n, slot->hist + l * hist_per_plane, c->stream);
             return WR_OK;
         };
+        auto plane_buf = [&](unsigned l) -> uint8_t* { return plane_prepare(c, (int)l, n, false) == WR_OK ? c->ps[l].dev : nullptr; };
         auto plane_ready = [&](unsigned l, bool) -> int {
-            // plane l and its histograms are complete on the device: off they go to pinned host memory, and a
-            // coder thread waits for them
-            if (int r = ensure_host_plane(c, (int)l, pitch)) return r;
+            // plane l and its histograms are complete on the device: the histograms go to pinned host memory, the
+            // plane's first chunk sets off into its ring, and a coder thread waits for them
             if (int r = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return r;
-            const Piece pc[2] = {{c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t)},
-                                 {c->h_plane[l], slot->planes + l * pitch, n}};
-            if (int r = xfer_start(c, &c->x_plane[l], pc, 2, kDown)) return r;
+            const Piece pc = {c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t)};
+            if (int r = xfer_start(c, &c->x_plane[l], &pc, 1, kDown)) return r;
+            plane_prefetch(c, (int)l);
             planes_started = l + 1;
             if (per_plane) workers.v.emplace_back(code_group, l, l + 1);
             return WR_OK;
@@ -1203,7 +1317,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         {
             // ---- stage "kernels"
             StageLock cu(pool->cu_mu);
-            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, slot->planes, info, &local, after_quant, plane_ready, &resid);
+            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, info, &local, after_quant, plane_ready, &resid);
             (void)hipStreamSynchronize(c->stream);
             if (rc == WR_OK && c->keep_residual && info->nlay && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
                 if (hipMemcpyAsync(fld.dev, resid, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
@@ -1211,27 +1325,26 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
                     rc = fail(WR_ERR_HIP, "residual copy failed");
             }
         }
-        // ---- stage "down": the plane downloads were started as the planes completed; the residual follows them
+        // ---- stage "down": the histograms were sent off as the planes completed; the residual follows them
         if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
             const Piece pc = {fld.host, resid, n * sizeof(double)};
             if ((rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) == WR_OK) rc = xfer_wait(&c->x_field);
         }
-        // The slot's plane buffers must not be reused before their downloads are done (the coder threads wait
+        // The slot's histogram buffer must not be reused before its downloads are done (the coder threads wait
         // for the same transfers; xfer_wait is safe to call from both sides).  With the coder pool, every plane
-        // is handed over the moment it is on the host.
+        // is handed over the moment its histograms are on the host.
         for (unsigned l = 0; l < planes_started; l++) {
             if (xfer_wait(&c->x_plane[l]) != WR_OK) copy_failed[l] = 1;
             if (pooled && rc == WR_OK && !copy_failed[l]) {
                 wrrc::PlaneJob& j = jobs[l];
                 j.kind = wrrc::PlaneJob::kEncode;
-                j.src = c->h_plane[l]; j.dst = c->enc_buf[l]; j.n = n; j.hist = c->h_hist + l * hist_per_plane;
+                j.src = nullptr; j.io = &c->ps[l].io; j.dst = c->enc_buf[l]; j.n = n; j.hist = c->h_hist + l * hist_per_plane;
                 wrrc::pool_submit(&j, 1, &batch);
                 jobs_submitted = l + 1;
             }
         }
-        for (unsigned l = 0; l < planes_started; l++) local.d2h_ms += (float)c->x_plane[l].ms;
         t_gpu_done = now();
-        // the slot goes back here: its planes are on the host
+        // the slot goes back here: the planes are in device buffers of their own
     } catch (const std::exception& e) {
         workers.join();
         wrrc::pool_wait(&batch);
@@ -1240,16 +1353,6 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     if (pooled) {
         wrrc::pool_wait(&batch);
         for (unsigned l = 0; l < jobs_submitted; l++) { lens[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
-        if (rc == WR_OK && verbose())  // wrappers.cpp:401-409, 430
-            for (unsigned l = 0; l < info->nlay; l++) {
-                const uint8_t* q = c->h_plane[l];
-                unsigned lo = q[0], hi = q[0];
-                for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-                char b[256];
-                snprintf(b, sizeof b, "imin=%u imax=%u med=%g\nlen_out_q=%lu ntot=%lu\n", lo, hi,
-                         q[n / 2] * info->deps_vec[l] + info->minval_vec[l], (unsigned long)lens[l], (unsigned long)n);
-                logs[l] = b;
-            }
     } else if (rc == WR_OK && !per_plane && info->nlay) {
         try {
             const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)encoder_threads());
@@ -1262,8 +1365,11 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     }
     workers.join();
     if (rc) return rc;
-    for (unsigned l = 0; l < info->nlay; l++)
-        if (copy_failed[l]) return fail(WR_ERR_HIP, "download of plane " + std::to_string(l) + " failed");
+    for (unsigned l = 0; l < info->nlay; l++) {
+        if (copy_failed[l] || c->ps[l].err) return fail(WR_ERR_HIP, "download of plane " + std::to_string(l) + " failed");
+        local.d2h_ms += (float)(c->x_plane[l].ms + c->ps[l].copy_ms);
+        if (verbose()) logs[l] = plane_log(c, (int)l, n, info, true, lens[l]);  // wrappers.cpp:401-409, 430
+    }
     const double t_coded = now();
     // concatenate the plane streams (wrappers.cpp:412-427); gigabytes at 1024^3, so one copier per plane
     size_t total = 0, offs[WR_NLAYMAX] = {0};
@@ -1294,8 +1400,9 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     return WR_OK;
 }
 
-// mode: the whole decode; or only its host half (range decoding into the context's plane staging, no field buffer
-// needed: wr_decode_begin); or only its device half on planes decoded before (wr_decode_finish_*)
+// mode: the whole decode; or only its host half (range decoding, every decoded chunk going straight to the plane's device
+// buffer: no field buffer and no slot needed, wr_decode_begin); or only its device half on planes decoded before
+// (wr_decode_finish_*)
 enum DecodeMode { kDecodeWhole, kDecodeBegin, kDecodeFinish };
 
 int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_info* info, const unsigned char* data_enc,
@@ -1312,7 +1419,6 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     if (mode != kDecodeBegin && !fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
-    const size_t pitch = wr_plane_pitch(n);
     wr_timings local; memset(&local, 0, sizeof local);
     if (mode == kDecodeFinish) local = c->pend_tm;
     DevPool* const pool = c->pool;
@@ -1330,24 +1436,26 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     if (info->wlev != 0 && info->wlev != kWavLvl) return fail(WR_ERR_ARG, "wlev must be 0 or 4");
     const bool host_half = mode != kDecodeFinish, device_half = mode != kDecodeBegin;
     if (host_half && verbose()) printf("Range decoding...\n");
-    HostPlanes staging(c);  // a finish finds the planes its begin parked in the context
-    for (int l = 0; l < nlay; l++) if (int rc = ensure_host_plane(c, l, pitch)) return rc;
-
     size_t off[WR_NLAYMAX + 1] = {0};
     for (int l = 0; l < nlay; l++) off[l + 1] = off[l] + info->len_enc_vec[l];
     if (off[nlay] > info->ntot_enc) return fail(WR_ERR_STREAM, "len_enc_vec exceeds ntot_enc");
     if (host_half && data_len && info->ntot_enc > data_len) return fail(WR_ERR_STREAM, "ntot_enc exceeds the length of the coded buffer");
 
+    PlaneHold planes(c);  // a finish finds the planes its begin parked in the context
+    if (host_half) {
+        c->pend_valid = false;  // whatever an earlier begin parked here is overwritten now
+        for (int l = 0; l < nlay; l++) if (int rc = plane_prepare(c, l, n, true)) return rc;
+    }
+    for (int l = 0; l < nlay; l++)
+        if (!c->ps[l].dev || c->ps[l].n != n) return fail(WR_ERR_ARG, "wr_decode_finish: the planes of the begin are gone");
+
     SlotNeed need;
     transform_need(nx, ny, nz, info->wlev ? -kWavLvl : 0, &need);
     if (fld.host) need.field_elems = n;
-    need.planes_bytes = pitch * WR_NLAYMAX;
 
     size_t got[WR_NLAYMAX] = {0};
     double coder_s[WR_NLAYMAX] = {0};
-    int up_err[WR_NLAYMAX] = {0};
     Sem sem(coder_threads());
-    const int dev = c->device;
     // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved, or the process-wide
     // coder pool (wr_set_coder_pool), whose workers interleave planes of several fields
     const bool pooled = wrrc::pool_threads() > 0;
@@ -1361,24 +1469,16 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             wrrc::JobBatch batch;
             for (int l = 0; l < nlay; l++) {
                 jobs[l].kind = wrrc::PlaneJob::kDecode;
-                jobs[l].src = data_enc + off[l]; jobs[l].src_len = info->len_enc_vec[l]; jobs[l].dst = c->h_plane[l]; jobs[l].n = n;
+                jobs[l].src = data_enc + off[l]; jobs[l].src_len = info->len_enc_vec[l]; jobs[l].dst = nullptr; jobs[l].io = &c->ps[l].io; jobs[l].n = n;
             }
             wrrc::pool_submit(jobs, nlay, &batch);
             wrrc::pool_wait(&batch);
             for (int l = 0; l < nlay; l++) { got[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
         }
-        // With a thread per plane the planes finish at different times (a leading plane of a smooth field
-        // decodes 2-3 times faster than a noise plane): if a slot is free right now (and not the last one),
-        // take it and let every thread upload its plane the moment it is decoded, while the later planes
-        // are still being decoded; the accumulate kernel then consumes them in plane order
-        // (wrappers.cpp:492-516 reorganised).  With grouped threads all planes of a group finish together,
-        // and the slot is only claimed afterwards.
-        const bool early = mode == kDecodeWhole && groups == nlay && nlay > 1 && slot.acquire(c, need, /*nowait=*/true, /*spare=*/1) == WR_OK;
-        if (early) g_stat[WR_STAT_EARLY_DECODES]++;
-        auto upload_plane = [&](int l) -> int {
-            const Piece pc = {slot->planes + l * pitch, c->h_plane[l], n};
-            return xfer_start(c, &c->x_plane[l], &pc, 1, kUp);
-        };
+        // Every decoded window of a plane goes to the plane's device buffer while the decoder fills the next one
+        // (chunk by chunk: wrappers.cpp:492-516 reorganised); the accumulate kernel consumes the
+        // planes in plane order afterwards.
+        if (host_half) g_stat[WR_STAT_EARLY_DECODES]++;
         {
             Workers workers;
             for (int g = 0; g < groups; g++)
@@ -1388,15 +1488,11 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
                     const double t = now();
                     const uint8_t* ins[WR_NLAYMAX];
                     uint8_t* syms[WR_NLAYMAX];
-                    for (int l = l0; l < l1; l++) { ins[l - l0] = data_enc + off[l]; syms[l - l0] = c->h_plane[l]; }
-                    wrrc::decode_planes(l1 - l0, ins, info->len_enc_vec + l0, syms, n, got + l0);
+                    const wrrc::PlaneWindow* ios[WR_NLAYMAX];
+                    for (int l = l0; l < l1; l++) { ins[l - l0] = data_enc + off[l]; syms[l - l0] = nullptr; ios[l - l0] = &c->ps[l].io; }
+                    wrrc::decode_planes(l1 - l0, ins, info->len_enc_vec + l0, syms, n, got + l0, ios);
                     for (int l = l0; l < l1; l++) coder_s[l] = now() - t;
                     sem.release();
-                    if (early) {
-                        (void)hipSetDevice(dev);
-                        for (int l = l0; l < l1; l++)
-                            if (got[l] == n && upload_plane(l) != WR_OK) up_err[l] = 1;
-                    }
                 });
         }
         int bad = -1;
@@ -1404,51 +1500,34 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             if (got[l] != n) bad = l;
             if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
         }
-        if (bad >= 0) {
-            if (early) for (int l = 0; l < nlay; l++) (void)xfer_wait(&c->x_plane[l]);
-            return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
-        }
+        if (bad >= 0) return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
         if (host_half) {
+            for (int l = 0; l < nlay; l++) {
+                if (c->ps[l].err) return fail(WR_ERR_HIP, "upload of plane " + std::to_string(l) + " failed");
+                local.h2d_ms += (float)c->ps[l].copy_ms;
+            }
             t_coded = now();
             local.transfer = (t_coded - t0) - local.rangecoder;
             if (local.transfer < 0) local.transfer = 0;
         }
-        if (!device_half) {  // the planes wait in the context's staging for wr_decode_finish_*
+        if (!device_half) {  // the planes wait in the context's device buffers for wr_decode_finish_*
             local.total = now() - t0;
             c->pend_tm = local;
             c->pend_valid = true;
-            staging.keep = true;
+            planes.keep = true;
             if (tm) *tm = local;
             return WR_OK;
         }
         if (host_half && verbose()) {  // wrappers.cpp:489, 503-510
-            for (int l = 0; l < nlay; l++) {
-                const uint8_t* q = c->h_plane[l];
-                unsigned lo = q[0], hi = q[0];
-                for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-                printf("ilay=%d\nimin=%u imax=%u med=%g\n", l, lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l]);
-            }
+            for (int l = 0; l < nlay; l++) fputs(plane_log(c, l, n, info, false, 0).c_str(), stdout);
             printf("Wavelet reconstruction...\n");
         }
-        if (!early) {
-            if ((rc = slot.acquire(c, need)) != WR_OK) return rc;
-            t_phase = now();
-        } else {
-            t_phase = t_coded;
-        }
-        if (!early)  // ---- stage "up": planes, pinned host -> device
-            for (int l = 0; l < nlay; l++)
-                if (upload_plane(l) != WR_OK) up_err[l] = 1;
-        for (int l = 0; l < nlay; l++) {
-            if (xfer_wait(&c->x_plane[l]) != WR_OK) up_err[l] = 1;
-            local.h2d_ms += (float)c->x_plane[l].ms;
-        }
-        for (int l = 0; l < nlay; l++)
-            if (up_err[l]) return fail(WR_ERR_HIP, "upload of plane " + std::to_string(l) + " failed");
+        if ((rc = slot.acquire(c, need)) != WR_OK) return rc;  // the planes are on the device already: no "up" stage
+        t_phase = now();
         wrk::DequantParams p;
         memset(&p, 0, sizeof p);
         p.nlay = nlay;
-        for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = slot->planes + l * pitch; }
+        for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = c->ps[l].dev; }
         double* d_fld = fld.host ? slot->field : fld.dev;
         {
             // ---- stage "kernels"
