@@ -17,7 +17,7 @@ at a time in an AVX-512 loop).  The device stages of the fields (upload / kernel
 slots per GPU, copies on the SDMA engines) overlap with one another and with the host coding inside the library.
 value = field megabytes (10^6 B) round-tripped per second, whole job (all ranks).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 8] [--pool -1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 12] [--pool -1]
                   [--resident]   (fields start and end in HBM instead: the round-1 measurement)
                   [--pool 0 --threads 1]   (no coder pool: every call codes its planes on its own thread)
 
@@ -133,17 +133,19 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
             mem = min(mem, int(m[0])) if mem else int(m[0])
     # 2 coder threads per field; an encoder thread idles a third of the time (decoding takes longer and
     # sets the period of a lane), hence 1.25 threads per CPU
-    # with the coder pool the lanes are not threads: one field in flight per CPU keeps the pool's queues full
-    by_cpu = int(cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
-    # host memory per field in flight: pinned plane staging of the two contexts + coded streams (1.4 field sizes,
-    # measured 1.32) + the pinned output field (host-to-host mode); HBM: the work-space slots only, or
-    # (resident mode) two field buffers per lane on top
-    # (host mode: the output fields come from a small pool -- two-phase decode -- so a lane costs its plane staging and
-    # coded streams only; the input field and the output pool are a fixed 1 + out_pool field sizes)
-    per_lane = 1.4 * field_bytes
+    # with the coder pool the lanes are not threads: a field in flight spends part of its time in copies and kernels and
+    # waiting for its slowest plane, so 1.5 fields in flight per CPU keep the pool's workers busy (16 lanes on 16 CPUs:
+    # 12.2 CPUs busy on average)
+    by_cpu = int(1.5 * cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
+    # host memory per field in flight: the coded streams only (two hand-over buffers and the coder's output, ~0.45 field
+    # sizes at the bench's tolerances) and the pinned rings (0.25 GiB) -- the quantized planes stay in HBM; the input
+    # field and the pool of output fields (two-phase decode) are a fixed 1 + out_pool field sizes in host-to-host mode.
+    # HBM per field in flight: the planes of its encoder and decoder contexts (up to 4 + 4 at the bench's tolerances =
+    # one field size) next to three work-space slots of 2.2 field sizes; resident mode: two field buffers per lane more
+    per_lane = 0.5 * field_bytes
     fixed = (1 + out_pool) * field_bytes if host_mode else 0
     by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
-    by_hbm = want if host_mode else int((0.92 * hbm_free - 3 * 3.3 * field_bytes) // (2 * field_bytes * ntols))
+    by_hbm = int((0.92 * hbm_free - 3 * 2.2 * field_bytes) // ((1.0 if host_mode else 3.0) * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / mem_share / 2 ** 30, 1) if mem else None,
                   "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
@@ -221,7 +223,7 @@ def main():
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=8, help="fields in flight per tolerance (a step codes jobs x tols fields); cut down to what the rank's CPUs and memory allow")
+    ap.add_argument("--jobs", type=int, default=12, help="fields in flight per tolerance (a step codes jobs x tols fields); cut down to what the rank's CPUs and memory allow")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
@@ -413,12 +415,26 @@ def main():
     if args.warmup:
         run_steps(args.warmup, False)
     barrier()
+    def throttled_s():  # time this cgroup's threads were runnable but held back by the CPU quota (cgroup v2)
+        try:
+            with open("/sys/fs/cgroup/cpu.stat") as fh:
+                for line in fh:
+                    if line.startswith("throttled_usec"):
+                        return int(line.split()[1]) * 1e-6
+        except OSError:
+            pass
+        return None
+    thr0 = throttled_s()
     cpu0 = sum(os.times()[:2])
+    idle0 = api.stat(api.STAT_POOL_IDLE_MS)
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
+    pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
+    thr1 = throttled_s()
+    throttled = (thr1 - thr0) / dt if thr0 is not None and thr1 is not None else None
     if dist is not None:
         t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -517,6 +533,9 @@ def main():
         except Exception:
             pass
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
+        out["pool_workers_idle"] = round(pool_idle, 2)  # of the pool's workers, how many were waiting for a job on average
+        if throttled is not None:
+            out["cpu_quota_throttled"] = round(throttled, 3)  # cgroup cpu.stat throttled time / wall time of the timed region
         if world == 1 and not args.no_cpu_baseline:
             # one field alone on the idle machine, a coder thread per plane: the latency a single
             # encoding_wrap / decoding_wrap caller sees (outside the timed region)

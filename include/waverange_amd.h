@@ -170,6 +170,7 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_EARLY_DECODES 0   /* decode calls that uploaded each plane as soon as it was decoded */
 #define WR_STAT_SLOTS_POPULATED 1 /* work-space slots that received device buffers */
 #define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
+#define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */
 unsigned long wr_stat(int what);
 
 /* One context per concurrent caller: (device, kernel stream, coded-stream buffers, and per plane a ring

@@ -55,18 +55,19 @@ def test_bench_batch_sizing():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     fb = 1024 ** 3 * 8
-    # fields resident in HBM: two field buffers per lane next to the three work-space slots
+    # fields resident in HBM: two field buffers and the planes of two contexts per lane next to the three work-space slots
     jobs, lim = bench.fit_jobs(5, 2, fb, 288 * 10 ** 9, host_mode=False)
     assert 1 <= jobs <= 5 and jobs <= max(1, lim["jobs_by_cpu"]) and jobs <= max(1, lim["jobs_by_hbm"])
-    assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 3.3 * fb) // (4 * fb))
+    assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (3.0 * fb * 2))
     # HBM nearly full: still one job, never zero
     assert bench.fit_jobs(5, 2, fb, 40 * 10 ** 9, host_mode=False)[0] == 1
-    # host buffer to host buffer (the default): HBM holds only the slots, host memory is what a lane costs
-    jobs, lim = bench.fit_jobs(5, 2, fb, 288 * 10 ** 9)
-    assert 1 <= jobs <= 5 and lim["jobs_by_hbm"] == 5 and jobs <= max(1, lim["jobs_by_host_mem"])
-    # with the coder pool a lane is not a thread: one field in flight per CPU
+    # host buffer to host buffer (the default): the planes of the fields in flight live in HBM (one field size per lane),
+    # the host holds their coded streams
+    jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9)
+    assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (1.0 * fb * 2)) and jobs <= max(1, lim["jobs_by_host_mem"])
+    # with the coder pool a lane is not a thread: 1.5 fields in flight per CPU
     jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True)
-    assert lim["jobs_by_cpu"] == int(lim["cpus_per_rank"] // 2)
+    assert lim["jobs_by_cpu"] == int(1.5 * lim["cpus_per_rank"] // 2)
 
 
 def test_bench_cpu_share_pinning():

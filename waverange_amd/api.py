@@ -175,7 +175,7 @@ def set_device_slots(device, nslots):
     _check(lib().wr_set_device_slots(int(device), int(nslots)))
 
 
-STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES = 0, 1, 2
+STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDLE_MS = 0, 1, 2, 3
 
 
 def stat(what):

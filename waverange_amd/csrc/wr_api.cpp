@@ -723,7 +723,11 @@ void wr_set_verbosity(int level) { g_verbose.store(level ? 1 : 0); }
 void wr_set_threads(int nthreads) { g_threads.store(nthreads < 1 ? 1 : nthreads); g_enc_threads.store(0); }
 void wr_set_encoder_threads(int nthreads) { g_enc_threads.store(nthreads < 0 ? 0 : nthreads); }
 void wr_set_writeback_residual(int on) { g_writeback.store(on ? 1 : 0); }
-unsigned long wr_stat(int what) { return (what >= 0 && what < 4) ? g_stat[what].load() : 0; }
+unsigned long wr_stat(int what)
+{
+    if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
+    return (what >= 0 && what < 4) ? g_stat[what].load() : 0;
+}
 void wr_set_coder_pool(int nthreads, int decoder_streams)
 {
     wrrc::pool_configure(nthreads < 0 ? 0 : nthreads, decoder_streams);

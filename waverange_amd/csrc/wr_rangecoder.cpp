@@ -1187,9 +1187,15 @@ private:
             if ((want == kAny || want == kDec) && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); if (got) *got = kDec; return j; }
             if ((want == kAny || want == kEnc) && !enc_q_.empty()) { PlaneJob* j = enc_q_.front(); enc_q_.pop_front(); if (got) *got = kEnc; return j; }
             if (!block || stop_) return nullptr;
+            const double t = now_s();
             cv_.wait(lk);
+            idle_s_ += now_s() - t;
         }
     }
+public:
+    double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
+private:
+    double idle_s_ = 0;  // worker time spent waiting for a job, all workers
     static void finish(PlaneJob* j, size_t result, double t0)
     {
         j->result = result;
@@ -1299,6 +1305,7 @@ private:
 
 void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
 int pool_threads() { return Pool::get().threads(); }
+double pool_idle_seconds() { return Pool::get().idle_seconds(); }
 void pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { Pool::get().submit(jobs, count, batch); }
 void pool_wait(JobBatch* batch)
 {
