@@ -162,12 +162,12 @@ void wr_set_coder_pool(int nthreads, int decoder_streams);
 void wr_set_writeback_residual(int on);
 /* Work-space slots of a device (1..4, default 3 or WR_SLOTS): how many device phases may be in
  * flight at once -- one uploading, one in its kernels, one downloading.  A slot holds a staging
- * field, the coefficient array and 8 plane buffers (3.1 x the field size) and is only populated
- * when concurrent callers need it; if the device runs out of memory the library keeps to the
- * slots it has. */
+ * field, the coefficient array and the low-pass boxes of the transform (2.2 x the field size) and is
+ * only populated when concurrent callers need it; if the device runs out of memory the library keeps
+ * to the slots it has.  The quantized planes are not in the slot: see wr_ctx_create. */
 int wr_set_device_slots(int device, int nslots);
 /* process-wide event counters (diagnostics and tests) */
-#define WR_STAT_EARLY_DECODES 0   /* decode calls that uploaded each plane as soon as it was decoded */
+#define WR_STAT_EARLY_DECODES 0   /* decode calls whose planes went to the device window by window under the decoder */
 #define WR_STAT_SLOTS_POPULATED 1 /* work-space slots that received device buffers */
 #define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
 #define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */

@@ -4,15 +4,16 @@
 //   encoding_wrap : min/max -> forward transform -> bit-plane quantizer loop -> range coder
 //   decoding_wrap : range decoder -> dequantise-accumulate -> inverse transform
 // A call moves through three device stages on one of a few work-space SLOTS per GPU:
-//   up      host -> device   field (encode) or quantized planes (decode)       SDMA engine (wr_dma.h)
+//   up      host -> device   field (encode)                                     SDMA engine (wr_dma.h)
 //   kernels min/max, transform, quantizer / dequantizer                         the context's stream, one call
 //                                                                               at a time (DevPool::cu_mu)
-//   down    device -> host   planes + block histograms (encode) or field       SDMA engine
-// so that field k+1's upload and transform run under field k's plane download, and the host range
-// coder (one thread per plane, or fewer with the planes of a field interleaved in one loop:
-// wr_set_threads) starts on plane l the moment it is on the host.  Copies and kernels are ordered from
-// the host (HIP event of the producing kernel -> start the copy; signal of the copy -> launch the
-// consumer); pageable caller memory goes through hipMemcpyAsync on a copy stream instead.  Compiled with hipcc, strict IEEE
+//   down    device -> host   block histograms, residual (encode) or field       SDMA engine
+// The quantized planes are not part of the slot: they live in device buffers of their own (DevPlanes) and the host
+// range coder (one thread per plane, fewer with the planes of a field interleaved in one loop: wr_set_threads, or the
+// process-wide pool: wr_set_coder_pool) reads or writes them through a ring of two pinned 15 MB windows per plane
+// (PlaneStream, wrrc::PlaneWindow) while the slot already serves the next field.  Copies and kernels are ordered from
+// the host (HIP event of the producing kernel -> start the copy; signal of the copy -> launch the consumer); pageable
+// caller memory goes through hipMemcpyAsync on a copy stream instead.  Compiled with hipcc, strict IEEE
 // (-ffp-contract=off): the scalar arithmetic on deps/aopt/bopt/tolabs below must round exactly as
 // wrappers.cpp:292-340 does.
 #include <float.h>
@@ -129,8 +130,8 @@ constexpr int kMaxSlots = 4;
 }  // namespace
 
 // Per-GPU state shared by all contexts on it: the work-space slots (a 1024^3 slot is 8.6 GB each for
-// field staging, coefficients and planes, 1.2 GB of low-pass boxes; slots are populated on demand, so a
-// lone caller uses one), one copy stream per direction (copies of all contexts queue on them in call
+// field staging and coefficients, 1.2 GB of low-pass boxes; slots are populated on demand, so a
+// lone caller uses one), the pool of plane buffers, one copy stream per direction (copies of all contexts queue on them in call
 // order and stay off the streams that run kernels) and the stage locks.
 // Quantized planes live in DEVICE memory, in buffers shared by the contexts of one device: a call borrows one per
 // plane for as long as the plane exists (encode: quantized until coded; decode: from the first decoded symbol until the
