@@ -381,18 +381,21 @@ def test_two_phase_decode(ctx, api, oracle):
     assert np.array_equal(out, g)
 
 
-def test_small_windows_on_every_path():
+@pytest.mark.parametrize("env", [{"WR_WINDOW_BLOCKS": "1"}, {"WR_WINDOW_BLOCKS": "2", "WR_NO_DMA": "1"}],
+                         ids=["one_block_windows", "two_block_windows_hipMemcpyAsync"])
+def test_small_windows_on_every_path(env):
     """The planes reach the host coder through 15 MB windows of a pinned ring; with WR_WINDOW_BLOCKS=1 a window is one
     coder block (60000 symbols), so the small fields of the tests in this file and of the parity file cross dozens of
     window boundaries on every path (thread per plane, grouped threads, the pool, two-call decodes, the drop-in
-    symbols): run them again in a child process with that setting."""
+    symbols): run them again in a child process with that setting, and once more with the window copies on
+    hipMemcpyAsync and the copy streams (WR_NO_DMA=1: what happens without ROCr's DMA interface)."""
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("(codec or trivial or drop_in or local_cutoff or error_paths or concurrent_contexts or grouped_coder or random_shapes "
            "or zero_minimum or host_entry_points or plane_ordered or coder_pool or two_phase or beyond_the_launch "
            "or device_planes) and not (full_size or large_roundtrip or config4 or small_windows)")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_host_api.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-k", sel],
-                       env=dict(os.environ, WR_WINDOW_BLOCKS="1"), capture_output=True, text=True)
+                       env=dict(os.environ, **env), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 

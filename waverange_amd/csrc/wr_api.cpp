@@ -219,7 +219,8 @@ struct wr_ctx {
         wr_ctx* c = nullptr;
         uint8_t* dev = nullptr; size_t dev_bytes = 0;
         size_t n = 0;
-        uint8_t* buf[2] = {nullptr, nullptr};  // pinned, kChunkSyms + 64 bytes each; allocated at first use, kept
+        uint8_t* buf[2] = {nullptr, nullptr};  // pinned (pageable if the host has no pinned memory left), allocated at first use, kept
+        bool buf_pinned[2] = {false, false};
         Xfer x[2];
         int cur = 1;                            // buffer of the window handed out last
         size_t win_first = 0, win_count = 0;    // decode: the window being filled
@@ -512,8 +513,15 @@ int plane_prepare(wr_ctx* c, int l, size_t n, bool decode)
         if (!b.p) return fail(WR_ERR_HIP, "out of device memory for a quantized plane (fewer calls in flight need less)");
         s.dev = b.p; s.dev_bytes = b.bytes;
     }
-    for (int b = 0; b < 2; b++)
-        if (!s.buf[b]) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s.buf[b]), kChunkBytes, hipHostMallocDefault));
+    for (int b = 0; b < 2; b++) {
+        if (s.buf[b]) continue;
+        if (hipHostMalloc(reinterpret_cast<void**>(&s.buf[b]), kChunkBytes, hipHostMallocDefault) == hipSuccess) { s.buf_pinned[b] = true; continue; }
+        // no pinned memory left: a pageable window works (the copies are then staged by the runtime, xfer_start)
+        (void)hipGetLastError();
+        s.buf[b] = static_cast<uint8_t*>(aligned_alloc(4096, (kChunkBytes + 4095) / 4096 * 4096));
+        s.buf_pinned[b] = false;
+        if (!s.buf[b]) return fail(WR_ERR_ARG, "out of host memory for a plane window");
+    }
     s.c = c; s.n = n;
     s.cur = 1; s.win_first = s.win_count = 0; s.ahead = false; s.ahead_first = 0; s.err = 0; s.copy_ms = 0;
     s.x[0].ms = s.x[1].ms = 0;
@@ -819,7 +827,8 @@ void wr_ctx_destroy(wr_ctx* c)
     for (int l = 0; l < WR_NLAYMAX; l++) {
         (void)xfer_wait(&c->ps[l].x[0]); (void)xfer_wait(&c->ps[l].x[1]);
         plane_release(c, l);
-        for (uint8_t* b : c->ps[l].buf) if (b) (void)hipHostFree(b);
+        for (int b = 0; b < 2; b++)
+            if (c->ps[l].buf[b]) { if (c->ps[l].buf_pinned[b]) (void)hipHostFree(c->ps[l].buf[b]); else free(c->ps[l].buf[b]); }
         free(c->enc_buf[l]);
     }
     for (int i = 0; i < WR_NLAYMAX; i++) {
