@@ -392,7 +392,7 @@ def test_small_windows_on_every_path(env):
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("(codec or trivial or drop_in or local_cutoff or error_paths or concurrent_contexts or grouped_coder or random_shapes "
            "or zero_minimum or host_entry_points or plane_ordered or coder_pool or two_phase or beyond_the_launch "
-           "or device_planes) and not (full_size or large_roundtrip or config4 or small_windows)")
+           "or device_planes or concurrent_host_calls) and not (full_size or large_roundtrip or config4 or small_windows)")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_host_api.py"),
                         os.path.join(here, "test_gpu_parity.py"), "-k", sel],
                        env=dict(os.environ, **env), capture_output=True, text=True)
