@@ -532,6 +532,7 @@ def main():
             out["host_peak_rss_gib"] = round(int(hwm[1]) / 2 ** 20, 2)
         except Exception:
             pass
+        out["hbm_planes_gib"] = round(api.stat(api.STAT_DEVICE_PLANE_BYTES) / 2 ** 30, 1)  # device buffers of quantized planes (in use + idle)
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
         out["pool_workers_idle"] = round(pool_idle, 2)  # of the pool's workers, how many were waiting for a job on average
         if throttled is not None:
