@@ -274,9 +274,8 @@ def main():
             dist.all_reduce(t)
             torch.cuda.synchronize()
 
-    # How many fields in flight this rank can afford: two coder threads (encoder stage, decoder stage) and
-    # ~2.45 field sizes of host memory per field (pinned plane staging, coded streams, the pinned output field).
-    # --jobs is the upper bound.
+    # How many fields in flight this rank can afford (fit_jobs): its share of the CPUs, of the host memory (coded
+    # streams) and the free HBM (the quantized planes of the fields in flight live there).  --jobs is the upper bound.
     share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
     jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
                             pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev)
