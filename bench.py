@@ -3,21 +3,25 @@
 host buffer (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; % HBM roofline; L-inf vs
 tol"; SURVEY.md 8d(1): the reference API takes and returns host arrays).
 
-One step = one batch of jobs x len(tols) fields per GPU (default 8 x 2: one field in flight per CPU of the rank,
-fewer if its CPUs or host memory are short).  Every field starts in a pinned host buffer and is encoded
-(upload; min/max, forward CDF-9/7, bit-plane quantizer on the GPU; planes D2H; rngcod13 range coder on the
-host -> coded bytes in host memory: wr_encode_host, what the drop-in encoding_wrap runs on) and decoded again
-(range decoder on the host: wr_decode_begin; planes H2D; dequantise + inverse transform on the GPU; download
-into a pinned host buffer: wr_decode_finish_host -- decoding_wrap does the two in one call; in two calls the
-output field is only held for the last quarter second, so four output buffers serve all lanes).  The range
-coder is one serial recurrence per plane and runs on the host by design, so the whole-job rate is set by the
-host cores a GPU has (16 on this pool): the plane streams of all fields in flight go to a pool of one coder
-thread per CPU, whose workers interleave 3-4 streams of any fields per symbol loop (dominant-symbol planes 16
-at a time in an AVX-512 loop).  The device stages of the fields (upload / kernels / download, three work-space
-slots per GPU, copies on the SDMA engines) overlap with one another and with the host coding inside the library.
+One step = one batch of fields per GPU (default 6 per tolerance setting = 12), K steps = K batches.  The fields of a
+run are pulled from one queue by jobs x len(tols) lanes (default 12 x 2: 1.5 fields in flight per CPU of the rank, fewer
+if its CPUs, host memory or HBM are short), so up to 24 fields are in flight and steps overlap; a lane is an encoder
+context and a decoder context with two coded-stream buffers between them: it encodes its next field while it decodes
+the previous one.  Every field starts in a pinned host buffer and is encoded (upload; min/max, forward CDF-9/7,
+bit-plane quantizer on the GPU, the planes staying in HBM; rngcod13 range coder on the host, which pulls the planes
+through pinned 15 MB windows -> coded bytes in host memory: wr_encode_host, what the drop-in encoding_wrap runs on)
+and decoded again (range decoder on the host, its windows going straight to the planes' device buffers:
+wr_decode_begin; dequantise + inverse transform on the GPU; download into a pinned host buffer:
+wr_decode_finish_host -- decoding_wrap does the two in one call; in two calls the output field is only held for the
+last quarter second, so four output buffers serve all lanes).  The range coder is one serial recurrence per plane
+and runs on the host by design, so the whole-job rate is set by the host cores a GPU has (16 on this pool): the
+plane streams of all fields in flight go to a pool of one coder thread per CPU, whose workers interleave 3-4
+streams of any fields per symbol loop (dominant-symbol planes 16 at a time in an AVX-512 loop).  The device stages
+of the fields (upload / kernels / download, three work-space slots per GPU, copies on the SDMA engines) overlap with
+one another and with the host coding inside the library.
 value = field megabytes (10^6 B) round-tripped per second, whole job (all ranks).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--jobs 12] [--pool -1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--tols 1e-3,1e-7] [--batch 12] [--jobs 12] [--pool -1]
                   [--resident]   (fields start and end in HBM instead: the round-1 measurement)
                   [--pool 0 --threads 1]   (no coder pool: every call codes its planes on its own thread)
 
@@ -137,12 +141,13 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # waiting for its slowest plane, so 1.5 fields in flight per CPU keep the pool's workers busy (16 lanes on 16 CPUs:
     # 12.2 CPUs busy on average)
     by_cpu = int(1.5 * cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
-    # host memory per field in flight: the coded streams only (two hand-over buffers and the coder's output, ~0.45 field
-    # sizes at the bench's tolerances) and the pinned rings (0.25 GiB) -- the quantized planes stay in HBM; the input
+    # host memory per field in flight: the coded streams only (two hand-over buffers that have each held a 1e-7 field's
+    # 2 GB at some point, and the coder's output while it is being produced: ~0.6 field sizes at the bench's tolerances,
+    # 0.75 budgeted) and the pinned rings (0.25 GiB) -- the quantized planes stay in HBM; the input
     # field and the pool of output fields (two-phase decode) are a fixed 1 + out_pool field sizes in host-to-host mode.
     # HBM per field in flight: the planes of its encoder and decoder contexts (up to 4 + 4 at the bench's tolerances =
     # one field size) next to three work-space slots of 2.2 field sizes; resident mode: two field buffers per lane more
-    per_lane = 0.5 * field_bytes
+    per_lane = 0.75 * field_bytes
     fixed = (1 + out_pool) * field_bytes if host_mode else 0
     by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
     by_hbm = int((0.92 * hbm_free - 3 * 2.2 * field_bytes) // ((1.0 if host_mode else 3.0) * field_bytes * ntols))
@@ -217,13 +222,15 @@ def cpu_baseline(size, tols, ncores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="fields a step codes (0: 6 per tolerance setting); the lanes pull fields from the run's "
+                    "queue, so up to --jobs x tols fields are in flight whatever the batch and steps overlap")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=12, help="fields in flight per tolerance (a step codes jobs x tols fields); cut down to what the rank's CPUs and memory allow")
+    ap.add_argument("--jobs", type=int, default=12, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
@@ -310,10 +317,12 @@ def main():
         orig.free()
         orig = None
     lanes = []
-    for i, tol in enumerate(tols * jobs):
+    batch = args.batch if args.batch > 0 else 6 * len(tols)
+    batch = max(len(tols), batch // len(tols) * len(tols))  # every step codes the same number of fields per tolerance
+    for i in range(len(tols) * jobs):
         ce = ctx if i == 0 else api.Context(dev_index)
         cd = api.Context(dev_index)
-        ln = dict(tol=tol, enc=ce, dec=cd, data=[np.empty(cap, dtype=np.uint8) for _ in range(2)])
+        ln = dict(enc=ce, dec=cd, data=[np.empty(cap, dtype=np.uint8) for _ in range(2)])
         if not host_mode:
             ln["work"], ln["rec"] = ce.alloc(nelem * 8), cd.alloc(nelem * 8)
         lanes.append(ln)
@@ -344,49 +353,76 @@ def main():
     errors = []
 
     def run_steps(nsteps, record):
-        """nsteps steps of every lane; returns when all of them have been encoded AND decoded."""
+        """nsteps steps = nsteps x batch fields (field i at tolerance tols[i % len(tols)]), pulled from one queue by the
+        lanes; returns when all of them have been encoded AND decoded."""
+        total = nsteps * batch
+        nxt = [0]
+
+        def next_field():
+            with lock:
+                i = nxt[0]
+                if i >= total:
+                    return None
+                nxt[0] = i + 1
+                return i
+
         ths = []
         for ln in lanes:
-            coded = [threading.Semaphore(0), threading.Semaphore(0)]  # slot holds a coded field
+            coded = [threading.Semaphore(0), threading.Semaphore(0)]  # slot holds a coded field (or the end mark)
             free = [threading.Semaphore(1), threading.Semaphore(1)]   # slot may be overwritten
             box = [None, None]
 
             def encoder(ln=ln, coded=coded, free=free, box=box):
+                k = 0
                 try:
-                    for k in range(nsteps):
+                    while True:
+                        i = next_field()
                         free[k & 1].acquire()
+                        if i is None or errors:
+                            box[k & 1] = None        # end mark for this lane's decoder
+                            coded[k & 1].release()
+                            return
+                        tol = tols[i % len(tols)]
                         if host_mode:
-                            enc, te = ln["enc"].encode_host(h_in, ln["tol"], out=ln["data"][k & 1])
+                            enc, te = ln["enc"].encode_host(h_in, tol, out=ln["data"][k & 1])
                         else:
                             ln["enc"].copy(ln["work"], orig, nelem * 8)
-                            enc, te = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][k & 1])
-                        box[k & 1] = (enc, te)
+                            enc, te = ln["enc"].encode(ln["work"], shape, tol, out=ln["data"][k & 1])
+                        box[k & 1] = (enc, te, tol, i)
                         coded[k & 1].release()
+                        k += 1
                 except Exception as exc:
                     errors.append(exc)
+                    box[0] = box[1] = None
                     for sem in coded:
                         sem.release()
 
             def decoder(ln=ln, coded=coded, free=free, box=box):
+                k = 0
                 try:
-                    for k in range(nsteps):
+                    while True:
                         coded[k & 1].acquire()
-                        if errors:
+                        item = box[k & 1]
+                        if item is None or errors:
                             return
-                        enc, te = box[k & 1]
+                        enc, te, tol, i = item
                         if host_mode:
                             ln["dec"].decode_begin(shape, enc)       # host range decoding: seconds, no field buffer
                             free[k & 1].release()                    # the coded stream is not needed any more
                             out = out_pool.get()
                             try:
-                                td = ln["dec"].decode_finish_host(out)  # upload, kernels, download: ~0.25 s
-                                if record and ln is lanes[-1] and k == nsteps - 1:
+                                td = ln["dec"].decode_finish_host(out)  # kernels, download: ~0.25 s
+                                if record and i == total - 1:
                                     accuracy["linf_rel"] = linf_vs_input(out)
                             finally:
                                 out_pool.put(out)
                         else:
                             td = ln["dec"].decode(ln["rec"], shape, enc)
+                            if record and i == total - 1:
+                                diff, amax = ln["dec"].linf(orig, ln["rec"], nelem)
+                                accuracy["linf_rel"] = diff / amax
                             free[k & 1].release()
+                        k += 1
                         if record:
                             with lock:
                                 for key, val in (("fwd_ms", te["transform_ms"]), ("inv_ms", td["transform_ms"]), ("quant_ms", te["quant_ms"]),
@@ -396,8 +432,8 @@ def main():
                                                  ("dec_wait_s", td["wait"]), ("enc_h2d_ms", te["h2d_ms"]), ("enc_d2h_ms", te["d2h_ms"]),
                                                  ("dec_h2d_ms", td["h2d_ms"]), ("dec_d2h_ms", td["d2h_ms"]), ("nlay", enc["nlay"])):
                                     acc[key].append(val)
-                                stats[ln["tol"]] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"],
-                                                    "bits_per_symbol": [round(8.0 * v / nelem, 3) for v in enc["len_enc_vec"]]}
+                                stats[tol] = {"nlay": enc["nlay"], "ntot_enc": enc["ntot_enc"],
+                                              "bits_per_symbol": [round(8.0 * v / nelem, 3) for v in enc["len_enc_vec"]]}
                 except Exception as exc:
                     errors.append(exc)
                     for sem in free:
@@ -440,16 +476,12 @@ def main():
         dt = float(t.item())
 
     # accuracy of the last reconstruction (tols[-1]) against the original
-    if host_mode:
-        linf_rel = accuracy.get("linf_rel")
-    else:
-        diff, amax = lanes[-1]["dec"].linf(orig, lanes[-1]["rec"], nelem)
-        linf_rel = diff / amax
+    linf_rel = accuracy.get("linf_rel")
 
     mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
     if rank == 0:
         field_mb = nelem * 8 / 1e6
-        total_mb = world * args.steps * len(lanes) * field_mb
+        total_mb = world * args.steps * batch * field_mb
         alg_bytes = 16.0 * box_elems(n)             # per direction (18.28 B/elem at 2^k sizes)
         fwd_ms, inv_ms = mean(acc["fwd_ms"]), mean(acc["inv_ms"])
         t_ms = 0.5 * (fwd_ms + inv_ms)
@@ -479,7 +511,9 @@ def main():
                        "field_shards": world,
                        "range_coder": ({"pool_workers": pool_workers, "decoder_streams_per_loop": args.dec_streams, "encoder_streams_per_loop": 3} if pool_workers
                                        else {"threads_per_call": {"encode": args.enc_threads or args.threads, "decode": args.threads}}),
-                       "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": len(lanes), "sizing": limits, "pipeline": "encode(k+1) overlaps decode(k)",
+                       "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": batch, "sizing": limits,
+                       "pipeline": "a step is a batch of %d fields (%d per tolerance); the %d lanes (encoder + decoder context each) pull fields from the run's queue, "
+                                   "so steps overlap: a lane encodes its next field while it decodes the previous one" % (batch, batch // len(tols), len(lanes)),
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -544,13 +578,13 @@ def main():
             ln = lanes[-1]
             if host_mode:
                 out1 = out_pool.get()
-                enc1, te1 = ln["enc"].encode_host(h_in, ln["tol"], out=ln["data"][0])
+                enc1, te1 = ln["enc"].encode_host(h_in, tols[-1], out=ln["data"][0])
                 td1 = ln["dec"].decode_host(out1, enc1)
             else:
                 ln["enc"].copy(ln["work"], orig, nelem * 8)
-                enc1, te1 = ln["enc"].encode(ln["work"], shape, ln["tol"], out=ln["data"][0])
+                enc1, te1 = ln["enc"].encode(ln["work"], shape, tols[-1], out=ln["data"][0])
                 td1 = ln["dec"].decode(ln["rec"], shape, enc1)
-            out["single_field"] = {"tol": ln["tol"], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
+            out["single_field"] = {"tol": tols[-1], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
                                    "decode_s": round(td1["total"], 3),
                                    "MBps": round(field_mb / (te1["total"] + td1["total"]), 1)}
             api.set_threads(args.threads, args.enc_threads)

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <chrono>
@@ -1401,6 +1402,12 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         if (info->nlay) memcpy(data_enc, c->enc_buf[0], lens[0]);
     } catch (const std::exception&) {  // no thread to be had: copy here
         for (unsigned l = 0; l < info->nlay; l++) memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]);
+    }
+    // The per-plane coder output has been copied out: hand its pages back (only coded bytes were ever touched, but a
+    // noise plane's gigabyte would otherwise stay resident in every context that once coded one)
+    for (unsigned l = 0; l < info->nlay; l++) {
+        const uintptr_t a = ((uintptr_t)c->enc_buf[l] + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)c->enc_buf[l] + lens[l]) & ~(uintptr_t)4095;
+        if (e > a && e - a >= ((size_t)64 << 20)) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_DONTNEED);
     }
     if (verbose())
         for (unsigned l = 0; l < info->nlay; l++) fputs(logs[l].c_str(), stdout);
