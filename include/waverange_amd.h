@@ -256,10 +256,11 @@ int wr_encode_host(wr_ctx *ctx, double *h_fld, int nx, int ny, int nz, int wtfla
 int wr_decode_host(wr_ctx *ctx, double *h_fld, int nx, int ny, int nz, const wr_enc_info *info,
                    const unsigned char *data_enc, size_t data_len, wr_timings *tm);
 /* Decode in two calls, for callers that want to bound their output buffers: the host range decoding takes seconds
- * and needs no field buffer -- wr_decode_begin runs it into the context's plane staging -- the field buffer is only
- * touched by the ~0.2 s of upload, kernels and download that wr_decode_finish_host / _device run.  (A streaming
- * decoder with many fields in flight holds one output field per finish in progress instead of one per field.)
- * One begin may be pending per context; data_enc is not needed after begin has returned. */
+ * and needs no field buffer -- wr_decode_begin runs it, every decoded window going straight to the planes' device
+ * buffers, which stay parked in the context -- the field buffer is only touched by the ~0.2 s of kernels and
+ * download that wr_decode_finish_host / _device run.  (A streaming decoder with many fields in flight holds one
+ * output field per finish in progress instead of one per field.)  One begin may be pending per context (another
+ * begin, a whole decode or an encode on the context discards it); data_enc is not needed after begin has returned. */
 int wr_decode_begin(wr_ctx *ctx, int nx, int ny, int nz, const wr_enc_info *info,
                     const unsigned char *data_enc, size_t data_len, wr_timings *tm);
 int wr_decode_finish_host(wr_ctx *ctx, double *h_fld, wr_timings *tm);
