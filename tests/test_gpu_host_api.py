@@ -372,6 +372,12 @@ def test_two_phase_decode(ctx, api, oracle):
             api.set_coder_pool(0)
     with pytest.raises(api.WaveRangeError, match="without a wr_decode_begin"):
         ctx.decode_finish_host(np.empty(f.shape))
+    # an encode on the context takes the planes a begin parked there: the finish says so instead of decoding garbage
+    ctx.decode_begin(f.shape, want)
+    enc2, _ = ctx.encode_host(f.copy(), 1e-7)
+    same_as_oracle(enc2, want)
+    with pytest.raises(api.WaveRangeError, match="without a wr_decode_begin"):
+        ctx.decode_finish_host(np.empty(f.shape))
     # trivial field through the two calls
     g = np.full((4, 5, 6), 2.5)
     e, _ = ctx.encode_host(g, 1e-6)
