@@ -4,6 +4,7 @@
 
 #include <immintrin.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace wrrc {
 
@@ -158,7 +159,8 @@ void vec_decode_block(VecBlock* b, VecOther other)
         if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
 }
 
-void vec_encode_block(VecEncBlock* b)
+template <bool ALWAYS>
+static void vec_encode_block_t(VecEncBlock* b)
 {
     const __mmask16 act = (__mmask16)b->active;
     const __m512i vbottom = _mm512_set1_epi32((int)kBottom), vtopm1 = _mm512_set1_epi32((int)(kTop - 1));
@@ -173,24 +175,77 @@ void vec_encode_block(VecEncBlock* b)
     }
     const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
     const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
+    const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4), v255 = _mm512_set1_epi32(0xff);
+    // byte swap inside every 32-bit lane (vpshufb works per 128-bit lane; the pattern repeats)
+    const __m512i bswap = _mm512_broadcast_i32x4(_mm_set_epi8(12, 13, 14, 15, 8, 9, 10, 11, 4, 5, 6, 7, 0, 1, 2, 3));
 
-    uint8_t* out[kVecLanes];
-    size_t pos[kVecLanes];
+    // Bytes leave the way rangecod.c:182-207 lets them: the last byte shifted out of `low` is held back (`held`), together
+    // with the number of 0xff bytes that followed it (`ffs`), until the next byte shows whether a carry reaches them; so
+    // nothing that has been written is ever touched again.  The scalar code around this loop writes every byte at once
+    // and walks back on a carry; on entry the lane's last byte (and the 0xff bytes behind it, if any) are therefore
+    // taken back from the stream, and on exit they are written out again.
+    // Final bytes collect in the lane's 32-bit `pend` (count in `cnt`); when a lane holds four, all lanes store theirs
+    // with one unaligned 4-byte store each (what lies beyond a lane's `cnt` is overwritten by its next store).
     const uint8_t* in[kVecLanes];
     static const uint8_t zeros[16] = {0};
-    uint8_t dummy[8];  // idle lanes store their byte here (and never advance)
+    alignas(64) uint8_t dummy[64];  // idle lanes store here (and never advance)
+    alignas(64) uint64_t addr[kVecLanes];  // next write address of every lane
+    alignas(64) uint32_t hbuf[kVecLanes], fbuf[kVecLanes], vbuf[kVecLanes], tc[kVecLanes];
     for (int j = 0; j < kVecLanes; j++) {
         const bool on = act >> j & 1;
-        out[j] = on ? b->out[j] : dummy; pos[j] = on ? b->pos[j] : 0; in[j] = on ? b->sym[j] : zeros;
+        hbuf[j] = fbuf[j] = 0;
+        addr[j] = (uint64_t)(uintptr_t)dummy;
+        in[j] = zeros;
+        if (!on) continue;
+        size_t p = b->pos[j] - 1;
+        while (p > 0 && b->out[j][p] == 0xff) { fbuf[j]++; p--; }
+        hbuf[j] = b->out[j][p];
+        addr[j] = (uint64_t)(uintptr_t)(b->out[j] + p);
+        in[j] = b->sym[j];
     }
-    alignas(16) uint8_t bytes[16];
-    alignas(64) uint32_t tc[kVecLanes];
+    __m512i alo = _mm512_load_si512(addr), ahi = _mm512_load_si512(addr + 8);
+    __m512i held = _mm512_load_si512(hbuf), ffs = _mm512_load_si512(fbuf);
+    __m512i pend = _mm512_setzero_si512(), cnt = _mm512_setzero_si512();
     __m128i rows[16];
+
+    auto flush_all = [&]() {
+        // first byte out in the most significant position, then byte-swapped: it lands at the lowest address
+        const __m512i val = _mm512_shuffle_epi8(_mm512_sllv_epi32(pend, _mm512_slli_epi32(_mm512_sub_epi32(four, cnt), 3)), bswap);
+        _mm512_store_si512(vbuf, val);
+        _mm512_store_si512(addr, alo);
+        _mm512_store_si512(addr + 8, ahi);
+#pragma GCC unroll 16
+        for (int j = 0; j < kVecLanes; j++) memcpy(reinterpret_cast<void*>((uintptr_t)addr[j]), &vbuf[j], 4);  // one unaligned 4-byte store
+        alo = _mm512_add_epi64(alo, _mm512_cvtepu32_epi64(_mm512_castsi512_si256(cnt)));
+        ahi = _mm512_add_epi64(ahi, _mm512_cvtepu32_epi64(_mm512_extracti64x4_epi64(cnt, 1)));
+        pend = _mm512_setzero_si512();
+        cnt = _mm512_setzero_si512();
+    };
+    // lanes that put a byte out while 0xff bytes are held back (one byte in 256 is 0xff): held + carry, then the 0xff
+    // bytes (0x00 after a carry), straight to memory
+    auto emit_with_ffs = [&](unsigned lanes, __m512i carrybit) {
+        flush_all();
+        _mm512_store_si512(addr, alo);
+        _mm512_store_si512(addr + 8, ahi);
+        _mm512_store_si512(hbuf, held);
+        _mm512_store_si512(fbuf, ffs);
+        _mm512_store_si512(tc, carrybit);
+        do {
+            const int j = __builtin_ctz(lanes);
+            lanes &= lanes - 1;
+            uint8_t* p = reinterpret_cast<uint8_t*>((uintptr_t)addr[j]);
+            *p++ = (uint8_t)(hbuf[j] + tc[j]);
+            for (uint32_t k = 0; k < fbuf[j]; k++) *p++ = tc[j] ? 0x00 : 0xff;
+            addr[j] = (uint64_t)(uintptr_t)p;
+        } while (lanes);
+        alo = _mm512_load_si512(addr);
+        ahi = _mm512_load_si512(addr + 8);
+    };
 
     for (uint32_t i = 0; i < kBlockSyms; i++) {
         // ---- symbols in: every 16 steps, 16 bytes of each plane, transposed to one row per step
         if ((i & 15) == 0) {
-            for (int j = 0; j < kVecLanes; j++) rows[j] = _mm_loadu_si128(reinterpret_cast<const __m128i*>((act >> j & 1) ? in[j] + i : zeros));
+            for (int j = 0; j < kVecLanes; j++) rows[j] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in[j] + ((act >> j & 1) ? i : 0)));
             transpose16x16(rows);
         }
         const __m512i c = _mm512_cvtepu8_epi32(rows[i & 15]);
@@ -210,30 +265,32 @@ void vec_encode_block(VecEncBlock* b)
                 sy = _mm512_mask_set1_epi32(sy, (__mmask16)(1u << j), (int)e[1]);
             } while (miss);
         }
-        // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom put a byte out.  Branch-free for the
-        // usual single byte: every lane stores its candidate byte at its write position and advances by 0 or 1
-        // (as the scalar loop does), so that no data-dependent branch or scalar loop count sits between one
-        // step's range and the next; a pending carry and a second byte (symbol probability < 1/256) are rare.
+        // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom shift the top 9 bits out of `low`
+        // (ALWAYS: the step's renormalisation runs whether or not a lane shifts -- on planes of a bit per symbol some lane
+        // does in most steps, unpredictably, and the branch costs more than the dozen masked instructions)
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
-        for (;;) {
-            _mm_store_si128(reinterpret_cast<__m128i*>(bytes), _mm512_cvtepi32_epi8(_mm512_srli_epi32(low, 23)));
-            unsigned carry = _mm512_mask_test_epi32_mask(sh, low, _mm512_set1_epi32((int)kTop));
-            while (__builtin_expect(carry != 0, 0)) {  // "carry now", rangecod.c:191-195
-                const int j = __builtin_ctz(carry);
-                carry &= carry - 1;
-                size_t p = pos[j] - 1;
-                while (++out[j][p] == 0) p--;
+        while (ALWAYS || sh) {
+            if (__builtin_expect(_mm512_cmpeq_epu32_mask(cnt, four) != 0, 0)) flush_all();
+            const __m512i v9 = _mm512_srli_epi32(low, 23);                 // carry bit (bit 8) + byte
+            const __mmask16 isff = _mm512_mask_cmpeq_epu32_mask(sh, v9, v255);
+            __mmask16 emit = sh & ~isff;
+            const __m512i carrybit = _mm512_srli_epi32(v9, 8);
+            const unsigned with_ffs = _mm512_mask_test_epi32_mask(emit, ffs, ffs);
+            if (__builtin_expect(with_ffs != 0, 0)) {
+                emit_with_ffs(with_ffs, carrybit);
+                emit &= (__mmask16)~with_ffs;
+                ffs = _mm512_maskz_mov_epi32((__mmask16)~with_ffs, ffs);
+                held = _mm512_mask_and_epi32(held, (__mmask16)with_ffs, v9, v255);
             }
-            const unsigned m = sh;
-#pragma GCC unroll 16
-            for (int j = 0; j < kVecLanes; j++) {
-                out[j][pos[j]] = bytes[j];
-                pos[j] += m >> j & 1;
-            }
+            const __m512i outb = _mm512_and_si512(_mm512_add_epi32(held, carrybit), v255);
+            pend = _mm512_mask_or_epi32(pend, emit, _mm512_slli_epi32(pend, 8), outb);
+            cnt = _mm512_mask_add_epi32(cnt, emit, cnt, one);
+            held = _mm512_mask_and_epi32(held, emit, v9, v255);
+            ffs = _mm512_mask_add_epi32(ffs, isff, ffs, one);
             low = _mm512_mask_and_epi32(low, sh, _mm512_slli_epi32(low, 8), vtopm1);
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
-            if (__builtin_expect(sh == 0, 1)) break;
+            sh = _mm512_cmple_epu32_mask(range, vbottom) & act;  // a second byte: symbol probability < 1/256
+            if (ALWAYS && __builtin_expect(sh == 0, 1)) break;
         }
         // ---- r = range / 60000; low += r * lt; range = r * sy, or what is left for the largest symbol (rangecod.c:217-229)
         const __m512i n5 = _mm512_srli_epi32(range, 5);
@@ -245,9 +302,36 @@ void vec_encode_block(VecEncBlock* b)
         const __mmask16 is_top = _mm512_cmpeq_epu32_mask(c, top);
         range = _mm512_mask_sub_epi32(_mm512_mullo_epi32(r, sy), is_top, range, t);
     }
+    // ---- back to the form the scalar code keeps: everything written, the held byte and its 0xff bytes included
+    flush_all();
     _mm512_mask_storeu_epi32(b->low, act, low);
     _mm512_mask_storeu_epi32(b->range, act, range);
-    for (int j = 0; j < kVecLanes; j++) if (act >> j & 1) b->pos[j] = pos[j];
+    _mm512_store_si512(addr, alo);
+    _mm512_store_si512(addr + 8, ahi);
+    _mm512_store_si512(hbuf, held);
+    _mm512_store_si512(fbuf, ffs);
+    for (int j = 0; j < kVecLanes; j++) {
+        if (!(act >> j & 1)) continue;
+        uint8_t* p = reinterpret_cast<uint8_t*>((uintptr_t)addr[j]);
+        *p++ = (uint8_t)hbuf[j];
+        for (uint32_t k = 0; k < fbuf[j]; k++) *p++ = 0xff;
+        b->pos[j] = (size_t)(p - b->out[j]);
+    }
+}
+
+void vec_encode_block(VecEncBlock* b)
+{
+    // how often does some lane shift a byte out?  A lane whose most probable symbol holds less than 97 % of the block
+    // puts out more than a byte per 40 symbols.
+    int busy = 0;
+    for (int j = 0; j < kVecLanes; j++) {
+        if (!(b->active >> j & 1)) continue;
+        uint32_t best = 0;
+        for (int e = 0; e < kVecCand; e++) if (b->sy[e][j] > best) best = b->sy[e][j];
+        if ((uint64_t)best * 100 < (uint64_t)kBlockSyms * 97) busy++;
+    }
+    if (busy >= 2) vec_encode_block_t<true>(b);
+    else vec_encode_block_t<false>(b);
 }
 
 }  // namespace wrrc
