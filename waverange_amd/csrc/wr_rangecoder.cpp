@@ -1281,9 +1281,10 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_;
-    // The encoder's vector loop is opt-in (WR_VEC_ENCODE=1): it codes 16 dominant-symbol planes at 0.8-2.2 Gsym/s per
-    // thread (scalar: 0.55-0.68), but every stream of the group advances at 50-140 Msym/s against ~180 in a scalar
-    // loop of three -- with few fields in flight their encode time is what counts (bench: 5.9 against 6.3 GB/s).
+    // The encoder's vector loop is opt-in (WR_VEC_ENCODE=1): it codes 16 dominant-symbol planes at 1.2-2.4 Gsym/s per
+    // thread (scalar: 0.57-0.74), but every stream of the group advances at 75-150 Msym/s against ~190 in a scalar
+    // loop of three, and in the pipeline its sessions settle half empty: the bench line does not move with it
+    // (profiles/r02/NOTES.md).
     const bool vec_enc_ = getenv("WR_VEC_ENCODE") && atoi(getenv("WR_VEC_ENCODE"));
     int venc_sessions_ = 0;
     const int venc_sessions_max_ = getenv("WR_VEC_ENC_SESSIONS") ? atoi(getenv("WR_VEC_ENC_SESSIONS")) : 64;

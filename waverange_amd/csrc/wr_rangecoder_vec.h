@@ -33,7 +33,8 @@ typedef uint32_t (*VecOther)(const void* model, uint32_t* low, uint32_t* range, 
 // One full block (60000 symbols) of up to 16 ENCODER streams whose blocks are held by at most four symbols (all but a
 // per cent or less): the encoder's dependency chain is only renormalise -> range / 60000 -> new range
 // (rangecod.c:182-229); the symbol's {lt, sy} come from four compares against the lane's candidates, a symbol outside
-// them takes a scalar table look-up on that lane; bytes leave per lane as they are produced.  (With gathers into the
+// them takes a scalar table look-up on that lane; the last byte shifted out and the 0xff bytes behind it are held back per
+// lane until the next byte decides about a carry (rangecod.c:182-207), final bytes leave in packed 4-byte stores.  (With gathers into the
 // lanes' tables instead of the compares the loop takes any plane, but was measured slower than the scalar loops on
 // all but the most skewed planes: two 16-lane gathers per step cost more than the whole scalar step.)
 struct VecEncBlock {
