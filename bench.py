@@ -462,12 +462,19 @@ def main():
     thr0 = throttled_s()
     cpu0 = sum(os.times()[:2])
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
+    loops0 = api.pool_loop_stats()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
     pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
+    loops1 = api.pool_loop_stats()
+    pool_loops = {}
+    for kind in loops1:  # in-pipeline rate of every coder loop: symbols per worker-second, workers busy in it on average
+        sec, blk = loops1[kind][0] - loops0[kind][0], loops1[kind][1] - loops0[kind][1]
+        if sec > 0:
+            pool_loops[kind] = {"Msym_per_worker_s": round(blk * 60000 / sec / 1e6, 1), "workers": round(sec / dt, 2)}
     thr1 = throttled_s()
     throttled = (thr1 - thr0) / dt if thr0 is not None and thr1 is not None else None
     if dist is not None:
@@ -567,6 +574,7 @@ def main():
             pass
         out["hbm_planes_gib"] = round(api.stat(api.STAT_DEVICE_PLANE_BYTES) / 2 ** 30, 1)  # device buffers of quantized planes (in use + idle)
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
+        out["pool_loops"] = pool_loops
         out["pool_workers_idle"] = round(pool_idle, 2)  # of the pool's workers, how many were waiting for a job on average
         if throttled is not None:
             out["cpu_quota_throttled"] = round(throttled, 3)  # cgroup cpu.stat throttled time / wall time of the timed region

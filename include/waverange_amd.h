@@ -172,6 +172,9 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
 #define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */
 unsigned long wr_stat(int what);
+/* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder, 16-lane encoder}: seconds the workers have
+ * spent in block steps of that loop and stream-blocks (60000 symbols) advanced: symbols per worker-second in the pipeline */
+void wr_pool_loop_stats(double *seconds4, double *blocks4);
 
 /* One context per concurrent caller: (device, kernel stream, coded-stream buffers, and per plane a ring
  * of two 15 MB pinned chunks), grown on demand and kept.  The device work space (wr_set_device_slots)

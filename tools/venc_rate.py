@@ -9,7 +9,7 @@ def plane(kind):
     if kind == "two": return rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.8, 0.2])
     if kind == "one": return np.where(rs.random_sample(n) < 0.9997, 128, rs.randint(120, 136, n)).astype(np.uint8)
     return np.minimum(rs.randint(0, 256, n), rs.randint(64, 320, n)).astype(np.uint8)
-for kind in ("two", "one"):
+for kind in ("two", "one", "noise"):
     ps3 = [plane(kind) for _ in range(3)]
     best = 1e9
     for _ in range(3):

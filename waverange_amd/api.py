@@ -119,6 +119,8 @@ def lib():
     L.wr_set_coder_pool.argtypes = [C.c_int, C.c_int]
     L.wr_stat.restype = C.c_ulong
     L.wr_stat.argtypes = [C.c_int]
+    L.wr_pool_loop_stats.restype = None
+    L.wr_pool_loop_stats.argtypes = [_vp, _vp]
     L.wr_range_encode_bound.restype = C.c_size_t
     L.wr_range_encode_bound.argtypes = [C.c_size_t]
     L.wr_range_encode.restype = C.c_size_t
@@ -180,6 +182,13 @@ STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDL
 
 def stat(what):
     return lib().wr_stat(int(what))
+
+
+def pool_loop_stats():
+    """{loop kind: (worker seconds in block steps, stream-blocks advanced)} since the process started."""
+    sec, blk = (C.c_double * 4)(), (C.c_double * 4)()
+    lib().wr_pool_loop_stats(sec, blk)
+    return {k: (sec[i], blk[i]) for i, k in enumerate(("scalar_encoder", "scalar_decoder", "vector_decoder", "vector_encoder"))}
 
 
 def set_writeback_residual(on):

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <memory>
@@ -380,14 +381,21 @@ public:
         uint32_t bs[kCap];
         VecEncBlock vb;
         vb.active = 0;
+        vb.gather = 0;
         vb.tab = &tabs_[0][0].lt;
+        const uint8_t* ss[kCap];
         for (int k = 0; k < count_; k++) {
             EncGroup::Stream& s = st_[k];
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
-            const uint8_t* ss = s.sym.at(s.done, s.n);
-            encode_block_header(*es_[k], ss, bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
-            // the four most frequent symbols of the block; the vector loop takes the block if they hold >= 99 % of it
+            ss[k] = s.sym.at(s.done, s.n);
+            encode_block_header(*es_[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
+            if (bs[k] != kBlock) {  // the final, partial block of a stream: scalar
+                if (bs[k]) encode_symbols<0, true>(*es_[k], ss[k], bs[k], tabs_[k], tops_[k]);
+                continue;
+            }
+            // the four most frequent symbols of the block; if they hold >= 99 % of every full block of this step the
+            // lanes pick {lt, sy} by comparing with them, otherwise all lanes gather them from their tables
             uint32_t cand[kVecCand], covered = 0;
             for (int e = 0; e < kVecCand; e++) {
                 int best = -1;
@@ -400,19 +408,14 @@ public:
                 cand[e] = best < 0 ? 0x100u : (uint32_t)best;
                 if (best >= 0) covered += tabs_[k][best].sy;
             }
-            if (bs[k] == kBlock && (uint64_t)covered * 100 >= (uint64_t)kBlock * 99) {
-                vb.active |= 1u << k;
-                vb.low[k] = es_[k]->low; vb.range[k] = es_[k]->range;
-                vb.sym[k] = ss; vb.out[k] = es_[k]->out; vb.pos[k] = es_[k]->pos; vb.top[k] = tops_[k];
-                for (int e = 0; e < kVecCand; e++) {
-                    vb.cand[e][k] = cand[e];
-                    vb.lt[e][k] = cand[e] < 256 ? tabs_[k][cand[e]].lt : 0;
-                    vb.sy[e][k] = cand[e] < 256 ? tabs_[k][cand[e]].sy : 0;
-                }
-            } else if (bs[k] == kBlock) {
-                encode_symbols<kBlock, true>(*es_[k], ss, kBlock, tabs_[k], tops_[k]);
-            } else if (bs[k]) {
-                encode_symbols<0, true>(*es_[k], ss, bs[k], tabs_[k], tops_[k]);
+            if ((uint64_t)covered * 100 < (uint64_t)kBlock * 99) vb.gather = 1;
+            vb.active |= 1u << k;
+            vb.low[k] = es_[k]->low; vb.range[k] = es_[k]->range;
+            vb.sym[k] = ss[k]; vb.out[k] = es_[k]->out; vb.pos[k] = es_[k]->pos; vb.top[k] = tops_[k];
+            for (int e = 0; e < kVecCand; e++) {
+                vb.cand[e][k] = cand[e];
+                vb.lt[e][k] = cand[e] < 256 ? tabs_[k][cand[e]].lt : 0;
+                vb.sy[e][k] = cand[e] < 256 ? tabs_[k][cand[e]].sy : 0;
             }
         }
         if (vb.active) {
@@ -1100,26 +1103,6 @@ size_t decode_plane(const uint8_t* in, size_t len, uint8_t* sym, size_t n)
 // =====================================================================================
 namespace {
 
-// do at most four symbols hold >= 99 % of the blocks of this plane?  (eight blocks across the plane are looked at)
-bool few_symbol_plane(const PlaneJob& j)
-{
-    const size_t nblocks = j.n / kBlock;
-    for (int s = 0; s < 8; s++) {
-        const size_t blk = nblocks * (size_t)s / 8;
-        uint32_t h[256];
-        if (j.hist) for (int v = 0; v < 256; v++) h[v] = j.hist[blk * 256 + v];
-        else if (j.io) return false;  // a windowed plane without histograms: not sampled
-        else histogram(j.src + blk * kBlock, kBlock, h);
-        uint32_t top4[4] = {0, 0, 0, 0};
-        for (int v = 0; v < 256; v++) {
-            uint32_t x = h[v];
-            for (int e = 0; e < 4; e++) if (x > top4[e]) { const uint32_t t = top4[e]; top4[e] = x; x = t; }
-        }
-        if ((uint64_t)(top4[0] + top4[1] + top4[2] + top4[3]) * 100 < (uint64_t)kBlock * 99) return false;
-    }
-    return true;
-}
-
 class Pool {
 public:
     static Pool& get() { static Pool p; return p; }
@@ -1154,9 +1137,9 @@ public:
             // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
             const bool vec = jobs[i].kind == PlaneJob::kDecode && vec_ok_ && jobs[i].n >= 4 * (size_t)kBlock &&
                              8 * jobs[i].src_len < 2 * jobs[i].n;
-            // encoder: planes whose blocks at most four symbols hold (sampled) take the vector loop
-            const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock &&
-                              few_symbol_plane(jobs[i]);
+            // encoder (opt-in): every plane takes the vector loop (candidate compares while all lanes of a session hold
+            // dominant-symbol blocks, gathers from the lanes' tables otherwise)
+            const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock;
             (vec ? vec_q_ : venc ? venc_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
@@ -1181,7 +1164,7 @@ private:
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
             }
             if (want == kVecEnc && !venc_q_.empty()) { PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); return j; }
-            if (want == kAny && !venc_q_.empty() && venc_sessions_ < venc_sessions_max_) {
+            if (want == kAny && !venc_q_.empty() && venc_sessions_ < venc_sessions_max()) {
                 PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); venc_sessions_++; if (got) *got = kVecEnc; return j;
             }
             if ((want == kAny || want == kDec) && !dec_q_.empty()) { PlaneJob* j = dec_q_.front(); dec_q_.pop_front(); if (got) *got = kDec; return j; }
@@ -1194,7 +1177,19 @@ private:
     }
 public:
     double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
+    // per loop kind (scalar encoder, scalar decoder, vector decoder, vector encoder): worker seconds spent in its block
+    // steps and stream-blocks (60000 symbols each, the last block of a stream counted whole) they advanced
+    void loop_stats(double seconds[4], double blocks[4])
+    {
+        for (int k = 0; k < 4; k++) { seconds[k] = loop_ns_[k].load() * 1e-9; blocks[k] = (double)loop_blocks_[k].load(); }
+    }
 private:
+    std::atomic<unsigned long long> loop_ns_[4] = {}, loop_blocks_[4] = {};
+    void account(int kind, double s, int nstreams)
+    {
+        loop_ns_[kind] += (unsigned long long)(s * 1e9);
+        loop_blocks_[kind] += (unsigned long long)nstreams;
+    }
     double idle_s_ = 0;  // worker time spent waiting for a job, all workers
     static void finish(PlaneJob* j, size_t result, double t0)
     {
@@ -1232,7 +1227,7 @@ private:
                         vg->add(j->src, j->src_len, j->dst, j->n, t, j->io);
                         j = vg->full() ? nullptr : pop(false, kVec);
                     }
-                    vg->step(on_end);
+                    { const int nstreams = vg->count(); const double ts = now_s(); vg->step(on_end); account(2, now_s() - ts, nstreams); }
                     if (!vg->full()) j = pop(false, kVec);
                 }
                 { std::lock_guard<std::mutex> lk(mu_); vec_sessions_--; }
@@ -1246,7 +1241,7 @@ private:
                         veg->add(j->src, j->n, j->dst, j->hist, t, j->io);
                         j = veg->full() ? nullptr : pop(false, kVecEnc);
                     }
-                    veg->step(on_end);
+                    { const int nstreams = veg->count(); const double ts = now_s(); veg->step(on_end); account(3, now_s() - ts, nstreams); }
                     if (!veg->full()) j = pop(false, kVecEnc);
                 }
                 { std::lock_guard<std::mutex> lk(mu_); venc_sessions_--; }
@@ -1260,7 +1255,7 @@ private:
                         dg->add(j->src, j->src_len, j->dst, j->n, t, j->io);
                         j = dg->full() ? nullptr : pop(false, kDec);
                     }
-                    dg->step(on_end);
+                    { const int nstreams = dg->count(); const double ts = now_s(); dg->step(on_end); account(1, now_s() - ts, nstreams); }
                     if (!dg->full()) j = pop(false, kDec);
                 }
             } else {
@@ -1271,7 +1266,7 @@ private:
                         eg.add(j->src, j->n, j->dst, j->hist, t, j->io);
                         j = eg.full() ? nullptr : pop(false, kEnc);
                     }
-                    eg.step(on_end);
+                    { const int nstreams = eg.count(); const double ts = now_s(); eg.step(on_end); account(0, now_s() - ts, nstreams); }
                     if (!eg.full()) j = pop(false, kEnc);
                 }
             }
@@ -1281,13 +1276,19 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_;
-    // The encoder's vector loop is opt-in (WR_VEC_ENCODE=1): it codes 16 dominant-symbol planes at 1.2-2.4 Gsym/s per
-    // thread (scalar: 0.57-0.74), but every stream of the group advances at 75-150 Msym/s against ~190 in a scalar
-    // loop of three, and in the pipeline its sessions settle half empty: the bench line does not move with it
-    // (profiles/r02/NOTES.md).
-    const bool vec_enc_ = getenv("WR_VEC_ENCODE") && atoi(getenv("WR_VEC_ENCODE"));
+    // The encoder's vector loop takes every plane (WR_VEC_ENCODE=0: scalar loops of three instead): 16 planes at 1.0-1.3
+    // Gsym/s per worker in the pipeline against 0.56 in the scalar loops.  Per stream it advances at 75-150 Msym/s against
+    // ~190, so the sessions are kept as many as leave a field's encode no longer than its decode (WR_VEC_ENC_SESSIONS;
+    // default 3/8 of the workers: 16 workers, 24 fields in flight: 6 sessions 11.3 GB/s, 4 sessions 9.4, scalar 9.4-9.7).
+    const bool vec_enc_ = !(getenv("WR_VEC_ENCODE") && !atoi(getenv("WR_VEC_ENCODE")));
     int venc_sessions_ = 0;
-    const int venc_sessions_max_ = getenv("WR_VEC_ENC_SESSIONS") ? atoi(getenv("WR_VEC_ENC_SESSIONS")) : 64;
+    const int venc_sessions_env_ = getenv("WR_VEC_ENC_SESSIONS") ? atoi(getenv("WR_VEC_ENC_SESSIONS")) : 0;
+    int venc_sessions_max() const  // call with mu_ held
+    {
+        if (venc_sessions_env_ > 0) return venc_sessions_env_;
+        const int w = (int)workers_.size();
+        return w < 3 ? 1 : (w * 3 + 4) / 8;
+    }
     const bool vec_ok_ = vec_available();
     int vec_sessions_ = 0;
     const int vec_sessions_env_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 0;
@@ -1295,7 +1296,7 @@ private:
     {
         if (vec_sessions_env_ > 0) return vec_sessions_env_;
         const int w = (int)workers_.size();
-        return w < 4 ? 1 : (w + 2) / 5;
+        return w < 4 ? 1 : (w * 5 + 8) / 16;  // 16 workers: 5 sessions (with the vector encoder: 11.3 GB/s; 3 sessions: 10.1)
     }
     std::vector<std::thread> workers_;
     bool stop_ = false;
@@ -1307,6 +1308,7 @@ private:
 void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
+void pool_loop_stats(double seconds[4], double blocks[4]) { Pool::get().loop_stats(seconds, blocks); }
 void pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { Pool::get().submit(jobs, count, batch); }
 void pool_wait(JobBatch* batch)
 {

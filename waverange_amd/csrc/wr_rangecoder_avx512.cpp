@@ -159,7 +159,7 @@ void vec_decode_block(VecBlock* b, VecOther other)
         if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
 }
 
-template <bool ALWAYS>
+template <bool ALWAYS, bool GATHER>
 static void vec_encode_block_t(VecEncBlock* b)
 {
     const __mmask16 act = (__mmask16)b->active;
@@ -176,6 +176,9 @@ static void vec_encode_block_t(VecEncBlock* b)
     const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
     const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
     const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4), v255 = _mm512_set1_epi32(0xff);
+    const __m512i lane_base = _mm512_setr_epi32(0, 256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304, 2560, 2816, 3072, 3328, 3584, 3840);
+    const __m512i pick_even = _mm512_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30);
+    const __m512i pick_odd = _mm512_setr_epi32(1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31);
     // byte swap inside every 32-bit lane (vpshufb works per 128-bit lane; the pattern repeats)
     const __m512i bswap = _mm512_broadcast_i32x4(_mm_set_epi8(12, 13, 14, 15, 8, 9, 10, 11, 4, 5, 6, 7, 0, 1, 2, 3));
 
@@ -249,21 +252,31 @@ static void vec_encode_block_t(VecEncBlock* b)
             transpose16x16(rows);
         }
         const __m512i c = _mm512_cvtepu8_epi32(rows[i & 15]);
-        // ---- {lt, sy} of the symbol: one of the lane's candidates, else the lane's table
-        const __mmask16 k1 = _mm512_cmpeq_epu32_mask(c, cand[1]), k2 = _mm512_cmpeq_epu32_mask(c, cand[2]), k3 = _mm512_cmpeq_epu32_mask(c, cand[3]);
-        const __mmask16 k0 = _mm512_cmpeq_epu32_mask(c, cand[0]);
-        __m512i lt = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(_mm512_mask_mov_epi32(clt[0], k1, clt[1]), k2, clt[2]), k3, clt[3]);
-        __m512i sy = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(_mm512_mask_mov_epi32(csy[0], k1, csy[1]), k2, csy[2]), k3, csy[3]);
-        unsigned miss = act & ~(k0 | k1 | k2 | k3);
-        if (__builtin_expect(miss != 0, 0)) {
-            _mm512_store_si512(tc, c);
-            do {
-                const int j = __builtin_ctz(miss);
-                miss &= miss - 1;
-                const uint32_t* e = b->tab + ((size_t)j * 256 + tc[j]) * 2;
-                lt = _mm512_mask_set1_epi32(lt, (__mmask16)(1u << j), (int)e[0]);
-                sy = _mm512_mask_set1_epi32(sy, (__mmask16)(1u << j), (int)e[1]);
-            } while (miss);
+        // ---- {lt, sy} of the symbol: one of the lane's candidates, else the lane's table; or (GATHER: planes of any
+        // statistics) two 8-lane gathers of the {lt, sy} pairs from the lanes' tables
+        __m512i lt, sy;
+        if (GATHER) {
+            const __m512i idx = _mm512_add_epi32(c, lane_base);  // lane * 256 + symbol: index of the 8-byte {lt, sy} entry
+            const __m512i p0 = _mm512_i32gather_epi64(_mm512_castsi512_si256(idx), b->tab, 8);
+            const __m512i p1 = _mm512_i32gather_epi64(_mm512_extracti64x4_epi64(idx, 1), b->tab, 8);
+            lt = _mm512_permutex2var_epi32(p0, pick_even, p1);
+            sy = _mm512_permutex2var_epi32(p0, pick_odd, p1);
+        } else {
+            const __mmask16 k1 = _mm512_cmpeq_epu32_mask(c, cand[1]), k2 = _mm512_cmpeq_epu32_mask(c, cand[2]), k3 = _mm512_cmpeq_epu32_mask(c, cand[3]);
+            const __mmask16 k0 = _mm512_cmpeq_epu32_mask(c, cand[0]);
+            lt = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(_mm512_mask_mov_epi32(clt[0], k1, clt[1]), k2, clt[2]), k3, clt[3]);
+            sy = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(_mm512_mask_mov_epi32(csy[0], k1, csy[1]), k2, csy[2]), k3, csy[3]);
+            unsigned miss = act & ~(k0 | k1 | k2 | k3);
+            if (__builtin_expect(miss != 0, 0)) {
+                _mm512_store_si512(tc, c);
+                do {
+                    const int j = __builtin_ctz(miss);
+                    miss &= miss - 1;
+                    const uint32_t* e = b->tab + ((size_t)j * 256 + tc[j]) * 2;
+                    lt = _mm512_mask_set1_epi32(lt, (__mmask16)(1u << j), (int)e[0]);
+                    sy = _mm512_mask_set1_epi32(sy, (__mmask16)(1u << j), (int)e[1]);
+                } while (miss);
+            }
         }
         // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom shift the top 9 bits out of `low`
         // (ALWAYS: the step's renormalisation runs whether or not a lane shifts -- on planes of a bit per symbol some lane
@@ -330,8 +343,9 @@ void vec_encode_block(VecEncBlock* b)
         for (int e = 0; e < kVecCand; e++) if (b->sy[e][j] > best) best = b->sy[e][j];
         if ((uint64_t)best * 100 < (uint64_t)kBlockSyms * 97) busy++;
     }
-    if (busy >= 2) vec_encode_block_t<true>(b);
-    else vec_encode_block_t<false>(b);
+    if (b->gather) vec_encode_block_t<true, true>(b);
+    else if (busy >= 2) vec_encode_block_t<true, false>(b);
+    else vec_encode_block_t<false, false>(b);
 }
 
 }  // namespace wrrc

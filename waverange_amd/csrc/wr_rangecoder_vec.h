@@ -46,6 +46,7 @@ struct VecEncBlock {
     uint32_t cand[kVecCand][kVecLanes], lt[kVecCand][kVecLanes], sy[kVecCand][kVecLanes];  // unused entries: cand = 0x100
     const uint32_t* tab;             // [16 lanes][256 symbols]{lt, sy}: symbols outside the candidates
     uint32_t top[kVecLanes];         // largest symbol present: its interval is open-ended (rangecod.c:227)
+    int gather;                      // != 0: {lt, sy} of every symbol gathered from `tab` (lanes with any statistics); else candidates
 };
 void vec_encode_block(VecEncBlock* b);
 
