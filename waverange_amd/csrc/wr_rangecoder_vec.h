@@ -30,13 +30,12 @@ struct VecBlock {
 // symbol outside the candidates (rare): the scalar look-up path on that lane's model
 typedef uint32_t (*VecOther)(const void* model, uint32_t* low, uint32_t* range, uint32_t help);
 
-// One full block (60000 symbols) of up to 16 ENCODER streams whose blocks are held by at most four symbols (all but a
-// per cent or less): the encoder's dependency chain is only renormalise -> range / 60000 -> new range
-// (rangecod.c:182-229); the symbol's {lt, sy} come from four compares against the lane's candidates, a symbol outside
-// them takes a scalar table look-up on that lane; the last byte shifted out and the 0xff bytes behind it are held back per
-// lane until the next byte decides about a carry (rangecod.c:182-207), final bytes leave in packed 4-byte stores.  (With gathers into the
-// lanes' tables instead of the compares the loop takes any plane, but was measured slower than the scalar loops on
-// all but the most skewed planes: two 16-lane gathers per step cost more than the whole scalar step.)
+// One full block (60000 symbols) of up to 16 ENCODER streams.  The encoder's dependency chain is only renormalise ->
+// range / 60000 -> new range (rangecod.c:182-229).  The symbol's {lt, sy} come from four compares against the lane's
+// most probable symbols while every lane's block is held by at most four symbols (all but a per cent or less; a symbol
+// outside them takes a scalar table look-up on that lane), or (`gather`) from two 8-lane gathers into the lanes' tables:
+// planes of any statistics.  The last byte shifted out and the 0xff bytes behind it are held back per lane until the
+// next byte decides about a carry (rangecod.c:182-207); final bytes leave in packed 4-byte stores.
 struct VecEncBlock {
     uint32_t active;                 // lane mask
     uint32_t low[kVecLanes], range[kVecLanes];
