@@ -1154,11 +1154,11 @@ private:
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            // at most vec_sessions_max() workers run a vector session at a time (WR_VEC_SESSIONS; default about a fifth
-            // of the workers): a session is worth its core with many lanes filled, so the dominant-symbol planes of
-            // all fields in flight are concentrated on a few workers (16 workers, 16 fields in flight, 40 such
-            // planes per step: 8.7 GB/s with three sessions, 8.4 with four, 8.2 without a limit, 6.8 with two, which
-            // cannot hold them all); what is queued beyond that joins a running session at its next block boundary
+            // at most vec_sessions_max() / venc_sessions_max() workers run a vector session of either kind at a time
+            // (WR_VEC_SESSIONS, WR_VEC_ENC_SESSIONS; default 5/16 and 3/8 of the workers): a session is worth its core
+            // with many lanes filled, but every stream in it advances the slower the fuller it is, so their number is
+            // what balances CPU time against the time a field waits for its planes (profiles/r02/NOTES.md); what is
+            // queued beyond that joins a running session at its next block boundary
             if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
             if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max()) {
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
