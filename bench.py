@@ -26,7 +26,12 @@ value = field megabytes (10^6 B) round-tripped per second, whole job (all ranks)
                   [--pool 0 --threads 1]   (no coder pool: every call codes its planes on its own thread)
 
 N > 1: one process per GPU (torch.distributed / RCCL for the timing barrier only); every rank
-codes its own independent field (seed 12345 + rank): weak scaling, no data-path collective.
+codes its own independent field (seed 12345 + rank): weak scaling, no data-path collective.  Either a
+launcher starts the ranks (the driver: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or -- `python bench.py --gpus N` on its own --
+this process starts them itself before it has touched the GPU, relays rank 0's line and exits with their status
+(launch_ranks).  --dry-launch: the ranks only report who they are (CPU check of the launcher).
+WR_BENCH_BACKEND=gloo rehearses N ranks on fewer GPUs (ranks share devices, barrier on CPU tensors).
 """
 import argparse
 import json
@@ -219,9 +224,52 @@ def cpu_baseline(size, tols, ncores):
                           "sample": "one %d^3 field per core on %d cores at once, same tols, %.1f s" % (size_all, ncores, dt_all)}}
 
 
+def launch_ranks(nranks, argv, dry):
+    """`python bench.py --gpus N` without a launcher around it: this process becomes the parent of N ranks.
+    It starts them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the contract of
+    torch.distributed.run) BEFORE anything here has touched the GPU -- no HIP call, no torch.cuda call that
+    initialises the device, no libwaverange_amd load -- relays what they print (rank 0 prints the JSON line) and
+    exits with the first non-zero status.  It never re-execs itself.  The analogue in the reference is one process
+    per subdomain started by a shell loop (examples/mssg/divided/all_enc_dec.sh:7-11)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("WR_BENCH_BACKEND", "nccl")
+    if not dry and backend == "nccl":
+        import torch  # device_count() reads the topology, it does not initialise a device
+        ndev = torch.cuda.device_count()
+        if ndev < nranks:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible; one rank per GPU (WR_BENCH_BACKEND=gloo rehearses "
+                             "more ranks than GPUs, the ranks then share devices)" % (nranks, ndev))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WR_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    status = 0
+    try:
+        for p in procs:
+            rc = p.wait()
+            if rc and not status:
+                status = rc
+                for q in procs:  # a rank that died would leave the others in the barrier for good
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    sys.exit(status)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true", help="ranks print RANK / WORLD_SIZE / the device they would take and exit "
+                    "(checks the launcher without a GPU)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="fields a step codes (0: 6 per tolerance setting); the lanes pull fields from the run's "
@@ -244,9 +292,23 @@ def main():
     n = args.size
     host_mode = not args.resident
 
+    # N ranks: under a launcher (the driver's torch.distributed.run) WORLD_SIZE is set and this process is one of
+    # them; started plainly with --gpus N > 1 this process is their parent (nothing below may run in it)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:], args.dry_launch)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+        if rank == 0:
+            print("bench.py: --gpus not given, following the launcher's WORLD_SIZE=%d" % world, file=sys.stderr)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+                          "launched_by": "bench.py" if os.environ.get("WR_BENCH_CHILD") else "external launcher" if world > 1 else "none"}), flush=True)
+        return
 
     import torch
     dist = None
@@ -516,6 +578,9 @@ def main():
                                       else "parity-size run"),
                        "boundary": "host buffers (pinned), wr_encode_host / wr_decode_begin + wr_decode_finish_host (%d output fields shared by the lanes)" % out_pool.qsize() if host_mode else "device buffers, wr_encode_device / wr_decode_device",
                        "field_shards": world,
+                       "multi_gpu": ("weak scaling: every rank round-trips its own stream of %d^3 fields (seed 12345 + rank) on its own GPU and its share of the "
+                                     "host cores, no data-path collective%s" % (n, "" if n == 512 else "; BASELINE configs[3] (NF = 8 x 512^3, one per GPU) is this with --size 512"))
+                       if world > 1 else None,
                        "range_coder": ({"pool_workers": pool_workers, "decoder_streams_per_loop": args.dec_streams, "encoder_streams_per_loop": 3} if pool_workers
                                        else {"threads_per_call": {"encode": args.enc_threads or args.threads, "decode": args.threads}}),
                        "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": batch, "sizing": limits,
