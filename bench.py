@@ -60,16 +60,67 @@ def measured_traffic(n):
     prescribes for gfx950), mean of forward and inverse.  Counters cannot be collected from inside this
     process, so the figure is the latest committed one and carries its file name; (None, None) if absent."""
     import glob
-    best, src = None, None
+    best, src, stale = None, None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_%d.json" % n))):
         try:
             with open(f) as fh:
                 t = json.load(fh)
             best = 0.5 * (t["fwd"]["total_bytes"] + t["inv"]["total_bytes"])
             src = os.path.relpath(f, ROOT)
+            # the file names the kernel sources it was measured on (tools/pmc_traffic.py); any edit since makes it stale
+            stale = t.get("kernel_sources_sha256") != kernel_sources_sha256()
         except Exception:
             pass
-    return best, src
+    return best, src, stale
+
+
+def kernel_sources_sha256():
+    """SHA-256 of the HIP sources whose kernels the PMC traffic figure belongs to."""
+    import hashlib
+    out = {}
+    for name in ("wr_fused.hip", "wr_kernels.hip"):
+        with open(os.path.join(ROOT, "waverange_amd", "csrc", name), "rb") as fh:
+            out[name] = hashlib.sha256(fh.read()).hexdigest()
+    return out
+
+
+def sha_big(a, chunk=1 << 28):
+    import hashlib
+    h = hashlib.sha256()
+    b = a.reshape(-1).view("uint8")
+    for o in range(0, b.size, chunk):
+        h.update(b[o:o + chunk])
+    return h.hexdigest()
+
+
+def parity_vs_pins(n, seed, coded, decoded):
+    """What the TIMED run produced against the reference's own outputs (tests/golden/large.json, written by
+    tools/make_golden_large.py from the compiled reference in the build container): the coded bytes of the last field
+    of every tolerance (header scalars as bit patterns, plane lengths, SHA-256 of data_enc) and the last reconstruction.
+    Runs after the timed region.  None where no pin exists for (size, tolerance, seed)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "large.json")) as fh:
+            pins = json.load(fh)
+    except OSError:
+        return {"fixture": None}
+    out = {"fixture": "tests/golden/large.json", "coded_sha_ok": None, "decoded_sha_ok": None, "checked": []}
+    for tol, enc in coded.items():
+        rec = pins.get("%d^3_tol%g" % (n, tol))
+        if not rec or rec["seed"] != seed:
+            continue
+        ok = (enc["nlay"] == rec["nlay"] and [int(v) for v in enc["len_enc_vec"]] == rec["len_enc_vec"] and int(enc["ntot_enc"]) == rec["ntot_enc"]
+              and all(float(enc[k]).hex() == rec[k] for k in ("tolabs", "midval", "halfspanval"))
+              and [float(v).hex() for v in enc["deps_vec"]] == rec["deps_vec"] and [float(v).hex() for v in enc["minval_vec"]] == rec["minval_vec"]
+              and sha_big(enc["data"][:rec["ntot_enc"]]) == rec["data_sha256"])
+        out["coded_sha_ok"] = ok if out["coded_sha_ok"] is None else (out["coded_sha_ok"] and ok)
+        out["checked"].append("coded %d^3 tol %g" % (n, tol))
+    if decoded is not None:
+        tol, arr = decoded
+        rec = pins.get("%d^3_tol%g" % (n, tol))
+        if rec and rec["seed"] == seed:
+            out["decoded_sha_ok"] = sha_big(arr) == rec["decoded_sha256"]
+            out["checked"].append("reconstruction %d^3 tol %g" % (n, tol))
+    return out
 
 
 def committed_extra(name):
@@ -407,6 +458,7 @@ def main():
             amax = max(amax, float(np.abs(a).max()))
         return diff / amax
 
+    last_coded, last_decoded = {}, []
     stats = {t: {} for t in tols}
     keys = ("fwd_ms", "inv_ms", "quant_ms", "dequant_ms", "minmax_ms", "enc_s", "dec_s", "enc_rc_s", "dec_rc_s", "enc_gpu_s",
             "dec_gpu_s", "enc_wait_s", "dec_wait_s", "enc_h2d_ms", "enc_d2h_ms", "dec_h2d_ms", "dec_d2h_ms", "nlay")
@@ -451,6 +503,8 @@ def main():
                             ln["enc"].copy(ln["work"], orig, nelem * 8)
                             enc, te = ln["enc"].encode(ln["work"], shape, tol, out=ln["data"][k & 1])
                         box[k & 1] = (enc, te, tol, i)
+                        if record and i >= total - len(tols):
+                            last_coded[tol] = enc   # its buffer is not written again: no field follows on any lane
                         coded[k & 1].release()
                         k += 1
                 except Exception as exc:
@@ -472,12 +526,15 @@ def main():
                             ln["dec"].decode_begin(shape, enc)       # host range decoding: seconds, no field buffer
                             free[k & 1].release()                    # the coded stream is not needed any more
                             out = out_pool.get()
+                            keep = False
                             try:
                                 td = ln["dec"].decode_finish_host(out)  # kernels, download: ~0.25 s
                                 if record and i == total - 1:
-                                    accuracy["linf_rel"] = linf_vs_input(out)
+                                    last_decoded.append((tol, out))  # held back: accuracy and parity are taken after the timed region
+                                    keep = True
                             finally:
-                                out_pool.put(out)
+                                if not keep:
+                                    out_pool.put(out)
                         else:
                             td = ln["dec"].decode(ln["rec"], shape, enc)
                             if record and i == total - 1:
@@ -544,7 +601,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # accuracy of the last reconstruction (tols[-1]) against the original
+    # accuracy of the last reconstruction (tols[-1]) against the original, and the bytes of the timed run against the
+    # reference's pins -- outside the timed region
+    parity = None
+    if host_mode and last_decoded:
+        accuracy["linf_rel"] = linf_vs_input(last_decoded[0][1])
+    if rank == 0 and host_mode:
+        parity = parity_vs_pins(n, 12345 + rank, last_coded, last_decoded[0] if last_decoded else None)
+    for _, buf in last_decoded:
+        out_pool.put(buf)
     linf_rel = accuracy.get("linf_rel")
 
     mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
@@ -555,7 +620,7 @@ def main():
         fwd_ms, inv_ms = mean(acc["fwd_ms"]), mean(acc["inv_ms"])
         t_ms = 0.5 * (fwd_ms + inv_ms)
         achieved = alg_bytes / (t_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(n)
+        traffic, traffic_src, traffic_stale = measured_traffic(n)
 
         def group(alg, ms):  # roofline of a kernel group from its algorithmic bytes and its HIP-event time
             gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -588,7 +653,7 @@ def main():
                                    "so steps overlap: a lane encodes its next field while it decodes the previous one" % (batch, batch // len(tols), len(lanes)),
                        "planes": {("%g" % t): stats[t] for t in tols}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": "3-D CDF-9/7 transform, 4 levels (mean of forward and inverse), all launches",
                          "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3)},
             # the other kernel groups: algorithmic bytes per element 17 L - 8 (quantizer, L planes), L + 8
@@ -612,6 +677,7 @@ def main():
                                 "field_d2h_GBps": round(nbytes_field / 1e6 / max(1e-9, mean(acc["dec_d2h_ms"])), 1) if host_mode else None},
                        "device_only_MBps": round(2 * field_mb / max(1e-9, mean(acc["enc_gpu_s"]) + mean(acc["dec_gpu_s"])), 1)},
             "accuracy": {"tol": tols[-1], "linf_rel": linf_rel},
+            "parity": parity,
         }
         # the same transform kernels back to back on a busy GPU (outside the timed region): what they do with the
         # shader clock up -- inside the pipeline every kernel stage starts on a GPU that has been idle

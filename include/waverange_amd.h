@@ -199,6 +199,12 @@ int wr_dev_download(wr_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
  * a staging copy (pageable buffers work everywhere too, at roughly half the rate) */
 int wr_host_alloc(void **ptr, size_t bytes);
 int wr_host_free(void *ptr);
+/* Pin a buffer the caller already owns (hipHostRegister): its copies then move by DMA without the runtime's staging
+ * copy.  They go through hipMemcpyAsync, not through the library's own SDMA path (the GPU sees registered memory at
+ * another address than the host does, which only HIP's copy translates): under many concurrent calls wr_host_alloc'd
+ * buffers are the faster choice.  Unregister before freeing the buffer. */
+int wr_host_register(void *ptr, size_t bytes);
+int wr_host_unregister(void *ptr);
 
 int wr_dev_copy(wr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); /* ctx stream, waits */
 /* measurement hook: copies through the compute units with `workgroups` workgroups on the context's stream, without
@@ -308,6 +314,13 @@ int wr_range_encode_windowed(int mode, int count, const unsigned char *const *sy
                              unsigned char *const *out, size_t *lens);
 int wr_range_decode_windowed(int mode, int count, const unsigned char *const *in, const size_t *len,
                              unsigned char *const *sym, size_t n, size_t chunk, size_t *produced);
+
+/* --- for callers with a batch of independent fields (the wrenc / wrdec / FluSI tools): starts the coder pool with one
+ * worker per CPU this process may use (affinity mask, cgroup quota) when nfields > 1, and returns how many
+ * encoding_wrap / decoding_wrap (or wr_*_host) calls on fields of field_elems elements to keep in flight at once:
+ * 1.5 per CPU, fewer if host memory or device memory are short, never more than nfields.  The calls themselves are
+ * unchanged (same bytes); this only sizes the concurrency around them. */
+int wr_autotune_batch(size_t field_elems, int nfields);
 
 /* --- measurement hook for bench.py: runs `reps` forward (lvl>0) or inverse transforms of an
  * nx*ny*nz field back to back on the context's stream and returns the average duration of

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <vector>
 #include "wr_rangecoder.h"
+#include "waverange_amd.h"  // the exported rngcod13 primitives (wr_compat.cpp): an encoder with block sizes of its own
 static unsigned long long s = 88172645463325252ull;
 static unsigned rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (unsigned)(s >> 11); }
 int main() {
@@ -186,6 +187,82 @@ int main() {
                     for (int k = 0; k < count; k++)
                         if (k != 1 && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("windowed: healthy stream disturbed\n"); return 1; }
                 }
+            }
+        }
+    }
+    // Streams whose blocks are shorter than 60000 symbols in MID-stream (the format allows them, the reference's encoder
+    // never writes them: built here from the exported rngcod13 primitives, block model of wrappers.cpp:85-128 with
+    // block sizes of our own).  Blocks then straddle window ends: whole-plane and windowed decoders must agree.
+    {
+        auto ragged_encode = [](const std::vector<uint8_t>& p, const std::vector<unsigned>& blocks, std::vector<uint8_t>* out) {
+            rangecoder rc;
+            init_databuf(&rc, 2 * p.size() + 600 * (blocks.size() + 2) + 1024);
+            start_encoding(&rc, 0, 0);
+            size_t at = 0;
+            for (unsigned bs : blocks) {
+                encode_freq(&rc, 1, 1, 2);
+                unsigned cnt[256] = {0}, cum[257];
+                for (unsigned i = 0; i < bs; i++) cnt[p[at + i]]++;
+                cum[0] = 0;
+                for (int b = 0; b < 256; b++) { encode_shift(&rc, 1, cnt[b], 16); cum[b + 1] = cum[b] + cnt[b]; }
+                for (unsigned i = 0; i < bs; i++) encode_freq(&rc, cnt[p[at + i]], cum[p[at + i]], bs);
+                at += bs;
+            }
+            encode_freq(&rc, 1, 0, 2);
+            done_encoding(&rc);
+            out->assign(rc.databuf, rc.databuf + rc.datapos);
+            free_databuf(&rc);
+        };
+        struct Win {
+            uint8_t* out; size_t n, chunk; uint8_t* cur; size_t cur_first, cur_count;
+            static uint8_t* fn(void* u, size_t first, size_t* count)
+            {
+                Win* w = (Win*)u;
+                if (w->cur) memcpy(w->out + w->cur_first, w->cur, w->cur_count);
+                delete[] w->cur; w->cur = nullptr;
+                if (*count == 0) return nullptr;
+                const size_t c = *count < w->chunk ? *count : w->chunk;
+                w->cur = new uint8_t[c]; w->cur_first = first; w->cur_count = c;
+                memset(w->cur, 0xEE, c);
+                *count = c;
+                return w->cur;
+            }
+        };
+        for (int trial = 0; trial < 6; trial++) {
+            const int count = 5;
+            const size_t n = (size_t)60000 * (4 + trial) + (trial % 2) * 4321;
+            std::vector<std::vector<uint8_t>> p(count), enc(count), whole(count), back(count);
+            std::vector<Win> wd(count);
+            std::vector<wrrc::PlaneWindow> iod(count);
+            std::vector<const wrrc::PlaneWindow*> pd(count);
+            std::vector<const uint8_t*> ip(count);
+            std::vector<uint8_t*> noned(count, nullptr);
+            std::vector<size_t> len(count), got(count), ns(count, n);
+            for (int k = 0; k < count; k++) {
+                p[k].resize(n); whole[k].assign(n, 0xEE); back[k].assign(n, 0xEE);
+                for (size_t i = 0; i < n; i++) { unsigned r = rnd(); p[k][i] = k % 3 == 0 ? r & 255 : k % 3 == 1 ? ((r & 15) ? 254 : 255) : (uint8_t)(100 + (r & 31)); }
+                std::vector<unsigned> blocks;
+                size_t left = n;
+                while (left) {  // full blocks, short ones (down to one symbol) and empty ones mixed
+                    unsigned r = rnd() % 8, bs = r < 4 ? 60000 : r == 4 ? 0 : 1 + rnd() % 60000;
+                    if (bs > left) bs = (unsigned)left;
+                    blocks.push_back(bs);
+                    left -= bs;
+                }
+                ragged_encode(p[k], blocks, &enc[k]);
+                len[k] = enc[k].size(); ip[k] = enc[k].data();
+                if (wrrc::decode_plane(enc[k].data(), len[k], whole[k].data(), n) != n || memcmp(whole[k].data(), p[k].data(), n)) {
+                    printf("ragged blocks: whole-plane decode failed trial=%d k=%d\n", trial, k); return 1;
+                }
+                wd[k] = Win{back[k].data(), n, (size_t)60000 * (1 + (k + trial) % 3), nullptr, 0, 0};
+                iod[k] = wrrc::PlaneWindow{Win::fn, &wd[k]}; pd[k] = &iod[k];
+            }
+            for (int mode = 0; mode < 2; mode++) {
+                for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
+                if (mode == 0) wrrc::decode_planes(count, ip.data(), len.data(), noned.data(), n, got.data(), pd.data());
+                else if (!wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data())) continue;
+                for (int k = 0; k < count; k++)
+                    if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("ragged blocks: windowed decode differs trial=%d mode=%d k=%d got=%zu\n", trial, mode, k, got[k]); return 1; }
             }
         }
     }

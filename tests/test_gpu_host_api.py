@@ -475,3 +475,67 @@ def test_host_api_error_paths(ctx, api):
     assert np.array_equal(again["data"], enc["data"])
     ctx.decode_host(out, enc)
     assert np.abs(out - f).max() <= 1.05e-6 * np.abs(f).max()
+
+
+def test_caller_registered_buffers(ctx, api, oracle):
+    """a field and an output the caller pinned itself (hipHostRegister through wr_host_register).  ROCr knows such
+    memory but the GPU sees it at another address; the library must not hand the host address to its SDMA path.  Big
+    enough (>= 1 MiB) for every bulk-copy path, wr_dev_upload / wr_dev_download included."""
+    f = synth.field(200, 120, 72, seed=31)
+    want = oracle.encode(f, 1e-8)
+    src, out = f.copy(), np.full_like(f, -1.0)
+    with api.registered(src), api.registered(out):
+        enc, _ = ctx.encode_host(src, 1e-8)
+        same_as_oracle(enc, want)
+        enc["data"] = enc["data"].copy()
+        ctx.decode_host(out, enc)
+        assert bits_equal(out, oracle.decode(want, f.shape))
+        ctx.set_keep_residual(True)   # the residual download into registered memory
+        try:
+            ctx.encode_host(src, 1e-8)
+        finally:
+            ctx.set_keep_residual(False)
+        assert bits_equal(src, want["residual"])
+        src[...] = f
+        dbuf = ctx.to_device(src)
+        back = np.empty_like(src)
+        with api.registered(back):
+            api._check(api.lib().wr_dev_download(ctx.h, back.ctypes.data, dbuf.ptr, back.nbytes))
+            assert bits_equal(back, f)
+        dbuf.free()
+
+
+def test_pool_stopped_under_running_calls(api, oracle):
+    """another thread stops the coder pool while calls are in flight: their planes are coded by the calls' own
+    threads instead of waiting for workers that are gone; the bytes stay the same."""
+    f = synth.field(160, 96, 64, seed=8)
+    want = oracle.encode(f, 1e-7)
+    errs = []
+
+    def caller():
+        try:
+            with api.Context(0) as c:
+                out = np.empty_like(f)
+                for _ in range(6):
+                    enc, _ = c.encode_host(f, 1e-7)
+                    same_as_oracle(enc, want)
+                    enc["data"] = enc["data"].copy()
+                    c.decode_host(out, enc)
+                    assert bits_equal(out, oracle.decode(want, f.shape))
+        except BaseException as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    api.set_coder_pool(4, 4)
+    try:
+        ths = [threading.Thread(target=caller) for _ in range(3)]
+        for t in ths:
+            t.start()
+        for k in range(12):   # the pool comes and goes under them
+            api.set_coder_pool(0 if k % 2 == 0 else 3, 4)
+        for t in ths:
+            t.join(timeout=300)
+            assert not t.is_alive(), "a call is stuck waiting for a pool that was stopped"
+    finally:
+        api.set_coder_pool(0)
+    if errs:
+        raise errs[0]

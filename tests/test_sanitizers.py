@@ -32,8 +32,8 @@ def test_range_coder_under_sanitizers():
         vec_o = os.path.join(d, "vec.o")
         subprocess.check_call(["g++"] + SAN + ["-mavx512f", "-mavx512bw", "-mavx512dq", "-mavx512vl", "-c",
                                                os.path.join(CSRC, "wr_rangecoder_avx512.cpp"), "-o", vec_o])
-        subprocess.check_call(["g++"] + SAN + ["-I" + CSRC, os.path.join(ROOT, "tests", "native", "rc_fuzz.cpp"),
-                                               os.path.join(CSRC, "wr_rangecoder.cpp"), vec_o, "-o", exe, "-lpthread"])
+        subprocess.check_call(["g++"] + SAN + ["-I" + CSRC, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "rc_fuzz.cpp"),
+                                               os.path.join(CSRC, "wr_rangecoder.cpp"), os.path.join(CSRC, "wr_compat.cpp"), vec_o, "-o", exe, "-lpthread"])
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert "sanitizer run OK" in r.stdout

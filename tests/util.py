@@ -56,3 +56,37 @@ def check_enc_record(e, rec, what=""):
     assert list(e["len_enc_vec"]) == rec["len_enc_vec"], what
     assert e["ntot_enc"] == rec["ntot_enc"], what
     assert sha(e["data"]) == rec["data_sha256"], what
+
+
+def sha_big(a, chunk=1 << 28):
+    """SHA-256 of an array's bytes without a copy of the whole array (fields of gigabytes)."""
+    h = hashlib.sha256()
+    b = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    for o in range(0, b.size, chunk):
+        h.update(b[o:o + chunk])
+    return h.hexdigest()
+
+
+def large_golden():
+    """tests/golden/large.json: outputs of the compiled reference at 512^3 and 1024^3 (tools/make_golden_large.py)."""
+    import json
+    with open(os.path.join(GOLDEN, "large.json")) as fh:
+        return json.load(fh)
+
+
+def check_large_record(e, rec, what=""):
+    """An encode result (dict with the encoding_wrap outputs and `data`) against a large.json record: header scalars as
+    bit patterns, plane lengths, SHA-256 of every plane stream and of all coded bytes."""
+    assert e["nlay"] == rec["nlay"] and e["wlev"] == rec["wlev"], what
+    assert list(int(v) for v in e["len_enc_vec"]) == rec["len_enc_vec"], (what, list(e["len_enc_vec"]), rec["len_enc_vec"])
+    assert int(e["ntot_enc"]) == rec["ntot_enc"], what
+    for k in ("tolabs", "midval", "halfspanval"):
+        assert float(e[k]).hex() == rec[k], (what, k)
+    assert hexes(e["deps_vec"]) == rec["deps_vec"], what
+    assert hexes(e["minval_vec"]) == rec["minval_vec"], what
+    data = np.ascontiguousarray(e["data"]).reshape(-1)[:rec["ntot_enc"]]
+    off = 0
+    for l, n in enumerate(rec["len_enc_vec"]):
+        assert sha_big(data[off:off + n]) == rec["plane_sha256"][l], (what, "coded bytes of plane %d differ from the reference's" % l)
+        off += n
+    assert sha_big(data) == rec["data_sha256"], what

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Reference-generated pins at the headline sizes -> tests/golden/large.json.
+
+Run in the build container only: it calls the REFERENCE ITSELF (oracle/_ref/libwaverange_ref.so, compiled from
+/root/reference/src by oracle/Makefile, strict-IEEE build) on the synthetic fields of BASELINE configs 2 and 3:
+
+    512^3  fp64, seed 12345, tol 1e-5 and 1e-7   (config 2; 1e-7 for a plane stream past 2^24 bytes)
+    1024^3 fp64, seed 12345, tol 1e-3 and 1e-7   (config 3: what bench.py round-trips)
+
+and records what encoding_wrap returned (header scalars as hex doubles, plane lengths, SHA-256 of data_enc and of
+every plane stream) and the SHA-256 of what decoding_wrap reconstructed.  These are the first reference-held pins
+where a plane stream is longer than the 24-bit bytecount trailer of rngcod13 can express
+(src/rangecod/rangecod.c:254-276) and a plane has 17 896 coding blocks.  The fixture is data: inputs are re-generated
+from the seed (guarded by their SHA-256), outputs are hashes and scalars.
+
+    python tools/make_golden_large.py [512:1e-5 512:1e-7 1024:1e-3 1024:1e-7]     (default: all four; ~27 GiB, ~25 min)
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import loader  # noqa: E402
+from waverange_amd import synth  # noqa: E402
+
+OUT = os.environ.get("WR_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden", "large.json"))
+SEED = 12345
+
+
+def sha_of(a, chunk=1 << 28):
+    h = hashlib.sha256()
+    b = a.reshape(-1).view(np.uint8)
+    for o in range(0, b.size, chunk):
+        h.update(b[o:o + chunk])
+    return h.hexdigest()
+
+
+def fill_field(out, n, seed):
+    """the synthetic field in z slabs (synth.field makes a dozen temporaries of its result's size)"""
+    step = max(1, (1 << 24) // (n * n))
+    for z in range(0, n, step):
+        out[z:z + step] = synth.field(n, n, n, seed, z, min(n, z + step))
+
+
+def run(impl_lib, which, n, tol):
+    """One encode + decode through `impl_lib` (the reference's or the oracle's entry points; `which` = 'ref' / 'oracle')
+    with no field-sized copies beyond the one array the API works in place on."""
+    dp, u8p, ulp = loader._dp, loader._u8p, loader._ulp
+    fld = np.empty((n, n, n), dtype=np.float64)
+    fill_field(fld, n, SEED)
+    rec = {"n": n, "tol": repr(tol), "seed": SEED, "input_sha256": sha_of(fld), "input_absmax": float(np.abs(fld).max()).hex()}
+    N = fld.size
+    data = np.empty(loader.NLAYMAX * max(1024, N), dtype=np.uint8)  # setup_wr's ntot_enc_max; only coded bytes get touched
+    cut = np.array([tol], dtype=np.float64)
+    tolabs, midval, halfspan = C.c_double(), C.c_double(), C.c_double()
+    wlev, nlay, ntot = C.c_ubyte(), C.c_ubyte(), C.c_ulong()
+    deps, mins, lens = np.zeros(8), np.zeros(8), np.zeros(8, dtype=np.uint64)
+    t0 = time.time()
+    enc = impl_lib.encoding_wrap if which == "ref" else impl_lib.wro_encode
+    enc(n, n, n, loader._p(fld, dp), 1, 1, 1, 1, loader._p(cut, dp), C.byref(tolabs), C.byref(midval), C.byref(halfspan),
+        C.byref(wlev), C.byref(nlay), C.byref(ntot), loader._p(deps, dp), loader._p(mins, dp), loader._p(lens, ulp), loader._p(data, u8p))
+    t1 = time.time()
+    L = nlay.value
+    hexf = lambda v: float(v).hex()  # noqa: E731
+    rec.update(tolabs=hexf(tolabs.value), midval=hexf(midval.value), halfspanval=hexf(halfspan.value), wlev=wlev.value, nlay=L,
+               ntot_enc=ntot.value, deps_vec=[hexf(v) for v in deps[:L]], minval_vec=[hexf(v) for v in mins[:L]],
+               len_enc_vec=[int(v) for v in lens[:L]], data_sha256=sha_of(data[:ntot.value]), residual_sha256=sha_of(fld))
+    off, planes = 0, []
+    for l in range(L):
+        planes.append(sha_of(data[off:off + int(lens[l])]))
+        off += int(lens[l])
+    rec["plane_sha256"] = planes
+    # a stream's last three bytes hold its length mod 2^24 (rangecod.c:272-275): which planes are past the wrap
+    rec["planes_past_2p24_bytes"] = [l for l in range(L) if int(lens[l]) >= 1 << 24]
+    if which == "ref":
+        impl_lib.decoding_wrap(n, n, n, loader._p(fld, dp), C.byref(tolabs), C.byref(midval), C.byref(halfspan), C.byref(wlev), C.byref(nlay),
+                               C.byref(ntot), loader._p(deps, dp), loader._p(mins, dp), loader._p(lens, ulp), loader._p(data, u8p))
+    else:
+        impl_lib.wro_decode(n, n, n, loader._p(fld, dp), midval.value, wlev.value, nlay.value, ntot.value, loader._p(deps, dp),
+                            loader._p(mins, dp), loader._p(lens, ulp), loader._p(data, u8p))
+    t2 = time.time()
+    rec["decoded_sha256"] = sha_of(fld)
+    ref_in = np.empty((n, n, n), dtype=np.float64)
+    fill_field(ref_in, n, SEED)
+    diff = 0.0
+    for z in range(0, n, 32):
+        diff = max(diff, float(np.abs(ref_in[z:z + 32] - fld[z:z + 32]).max()))
+    rec["linf_rel"] = diff / float.fromhex(rec["input_absmax"])
+    rec["seconds"] = {"encode": round(t1 - t0, 1), "decode": round(t2 - t1, 1)}
+    return rec
+
+
+def key(n, tol):
+    return "%d^3_tol%g" % (n, tol)
+
+
+def main():
+    cases = [(512, 1e-5), (512, 1e-7), (1024, 1e-3), (1024, 1e-7)]
+    if len(sys.argv) > 1:
+        cases = [(int(a.split(":")[0]), float(a.split(":")[1])) for a in sys.argv[1:]]
+    ref = loader.Reference()
+    out = {}
+    if os.path.exists(OUT):
+        with open(OUT) as fh:
+            out = json.load(fh)
+    out["_about"] = ("outputs of the compiled reference (oracle/_ref, strict IEEE: -ffp-contract=off) on waverange_amd.synth fields; "
+                     "written by tools/make_golden_large.py in the build container; hashes and scalars only")
+    fd = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    for n, tol in cases:
+        sys.stdout.flush()
+        os.dup2(devnull, 1)  # the reference prints progress lines from C++
+        try:
+            rec = run(ref.lib, "ref", n, tol)
+        finally:
+            sys.stdout.flush()
+            os.dup2(fd, 1)
+        out[key(n, tol)] = rec
+        print(key(n, tol), "nlay", rec["nlay"], "ntot_enc", rec["ntot_enc"], "lens", rec["len_enc_vec"], "linf_rel %.3g" % rec["linf_rel"], rec["seconds"], flush=True)
+        with open(OUT, "w") as fh:
+            json.dump(out, fh, indent=1, sort_keys=True)
+            fh.write("\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,12 @@ def main():
     out = {"size": n,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/prof_transform.py %d 2 both; last repetition" % n,
            "correction": "FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B for 16-B/lane streaming reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KiB = 1024 B"}
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out["kernel_sources_sha256"] = {}
+    for name in ("wr_fused.hip", "wr_kernels.hip"):  # bench.py marks the figure stale once these change
+        with open(os.path.join(here, "waverange_amd", "csrc", name), "rb") as fh:
+            out["kernel_sources_sha256"][name] = hashlib.sha256(fh.read()).hexdigest()
     for kind in ("fwd", "inv"):
         f, w = 2.0 * last_transform(fe, kind), last_transform(wr, kind)
         out[kind] = {"fetch_bytes": f, "write_bytes": w, "total_bytes": f + w}

@@ -114,6 +114,9 @@ def lib():
     L.wr_decode_finish_device.argtypes = [_vp, _vp, C.POINTER(Timings)]
     L.wr_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
     L.wr_host_free.argtypes = [_vp]
+    L.wr_host_register.argtypes = [_vp, C.c_size_t]
+    L.wr_autotune_batch.argtypes = [C.c_size_t, C.c_int]
+    L.wr_host_unregister.argtypes = [_vp]
     L.wr_set_device_slots.argtypes = [C.c_int, C.c_int]
     L.wr_set_writeback_residual.argtypes = [C.c_int]
     L.wr_set_coder_pool.argtypes = [C.c_int, C.c_int]
@@ -216,6 +219,21 @@ def pinned_array(shape, dtype=np.float64):
     buf = (C.c_ubyte * owner.nbytes).from_address(owner.ptr)
     buf._owner = owner  # keeps the allocation alive as long as the ctypes buffer (numpy's base)
     return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
+class registered:
+    """`with api.registered(arr):` pins a numpy array the caller owns for the duration of the block (wr_host_register)."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def __enter__(self):
+        _check(lib().wr_host_register(self.arr.ctypes.data, self.arr.nbytes))
+        return self.arr
+
+    def __exit__(self, *exc):
+        _check(lib().wr_host_unregister(self.arr.ctypes.data))
+        return False
 
 
 def range_encode_windowed(planes, chunk, mode=0):

@@ -6,6 +6,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 
@@ -65,8 +66,11 @@ void read_field(const std::string& path, int file_type, bool flip, const FieldSp
     }
     const size_t n = spec.count();
     const size_t nb = (size_t)spec.nbytes;
-    std::vector<unsigned char> raw(n * nb);
-    in.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(n * nb));
+    // the common layout (doubles in memory order, native endianness) goes straight into the field array
+    const bool direct = spec.nbytes == 8 && !flip && !spec.idinv;
+    std::unique_ptr<unsigned char[]> raw(direct ? nullptr : new unsigned char[n * nb]);
+    fld.resize(n);
+    in.read(direct ? reinterpret_cast<char*>(fld.data()) : reinterpret_cast<char*>(raw.get()), (std::streamsize)(n * nb));
     *pos += (long)(n * nb);
     if (ml) {  // trailing marker: read and discard  gen_aux.cpp:374-383
         unsigned char m[8];
@@ -74,10 +78,10 @@ void read_field(const std::string& path, int file_type, bool flip, const FieldSp
         *pos += ml;
     }
     if (in.fail()) die("Cannot read from " + path);  // gen_aux.cpp:389-395
-    fld.resize(n);
+    if (direct) return;
     const Inverted inv{(size_t)spec.nx, (size_t)spec.ny, (size_t)spec.nz, (size_t)spec.nh};
     for (size_t k = 0; k < n; k++) {
-        unsigned char* p = raw.data() + k * nb;
+        unsigned char* p = raw.get() + k * nb;
         if (flip) reverse_bytes(p, spec.nbytes);
         double v;
         if (spec.nbytes == 4) { float f; memcpy(&f, p, 4); v = f; }
@@ -101,16 +105,20 @@ void write_field(const std::string& path, bool first, int file_type, bool flip, 
     }
     const size_t n = spec.count();
     const size_t nb = (size_t)spec.nbytes;
-    std::vector<unsigned char> raw(n * nb);
-    const Inverted inv{(size_t)spec.nx, (size_t)spec.ny, (size_t)spec.nz, (size_t)spec.nh};
-    for (size_t k = 0; k < n; k++) {
-        const double v = fld[spec.idinv ? inv.mem_index(k) : k];
-        unsigned char* p = raw.data() + k * nb;
-        if (spec.nbytes == 4) { float f = (float)v; memcpy(p, &f, 4); }  // gen_aux.cpp:134-139
-        else memcpy(p, &v, 8);
-        if (flip) reverse_bytes(p, spec.nbytes);
+    if (spec.nbytes == 8 && !flip && !spec.idinv) {  // the common layout: the field array is the record
+        out.write(reinterpret_cast<const char*>(fld), (std::streamsize)(n * nb));
+    } else {
+        std::unique_ptr<unsigned char[]> raw(new unsigned char[n * nb]);
+        const Inverted inv{(size_t)spec.nx, (size_t)spec.ny, (size_t)spec.nz, (size_t)spec.nh};
+        for (size_t k = 0; k < n; k++) {
+            const double v = fld[spec.idinv ? inv.mem_index(k) : k];
+            unsigned char* p = raw.get() + k * nb;
+            if (spec.nbytes == 4) { float f = (float)v; memcpy(p, &f, 4); }  // gen_aux.cpp:134-139
+            else memcpy(p, &v, 8);
+            if (flip) reverse_bytes(p, spec.nbytes);
+        }
+        out.write(reinterpret_cast<char*>(raw.get()), (std::streamsize)(n * nb));
     }
-    out.write(reinterpret_cast<char*>(raw.data()), (std::streamsize)(n * nb));
     if (ml) out.write(reinterpret_cast<char*>(m), ml);  // gen_aux.cpp:207-222
 }
 

@@ -11,12 +11,14 @@
 #include <cstdlib>
 #include <fstream>
 #include <future>
+#include <thread>
 #include <iostream>
 #include <sstream>
 #include <string>
 #include <vector>
 
 #include "../../../include/waverange_amd.h"
+#include "batch.h"
 #include "gen_io.h"
 
 using std::cout;
@@ -251,15 +253,15 @@ int main(int argc, char** argv)
     { std::ofstream trunc(job.out_name, std::ios::binary | std::ios::out | std::ios::trunc); }
     if (job.file_type < 0 || job.file_type > 2) { cout << "Error: unknown file type" << endl; return 0; }
 
-    // Field pipeline: while field k is inside encoding_wrap on a worker thread (upload, GPU kernels, host
-    // range coder), the main thread reads field k+1 from the input file and writes field k-1's header
-    // record and coded bytes, always in field order.  `depth` fields are in flight (WR_CLI_PIPELINE,
-    // default 2: the library overlaps the device stages of one with the host coding of the other; 0 =
-    // strictly one after the other with the reference's order of log lines).
-    int depth = 2;
-    if (const char* e = getenv("WR_CLI_PIPELINE")) depth = atoi(e);
-    if (depth > job.nf - 1) depth = job.nf - 1;
-    if (depth < 0) depth = 0;
+    // Field pipeline.  The reference codes one field after the other (gen_enc.cpp:538-605); here up to `depth` fields
+    // are in flight: the main thread reads field k from the input file and hands it to a worker thread (min/max for the
+    // log, encoding_wrap: upload, GPU kernels, host range coder), a writer thread appends the header records and coded
+    // bytes of finished fields in field order.  With more than one field the library's coder pool codes the plane
+    // streams of all fields in flight on one worker per CPU, and says how many fields fit (wr_autotune_batch;
+    // WR_CLI_PIPELINE overrides; 0 = strictly one after the other with the reference's order of log lines).
+    size_t max_elems = 0;
+    for (const wrio::FieldSpec& s : job.fields) max_elems = std::max(max_elems, s.count());
+    int depth = wrcli::fields_in_flight(max_elems, job.nf);
     if (depth > 0) setenv("WR_QUIET", "1", 0);  // the library's progress lines of concurrent fields would interleave
     setenv("WR_WRITEBACK_RESIDUAL", "0", 0);    // the residual encoding_wrap leaves in the field array is not used here
 
@@ -269,15 +271,24 @@ int main(int argc, char** argv)
     struct Item {
         wrio::FieldHeader h;
         std::vector<double> fld;
-        std::vector<unsigned char> data_enc;
+        wrcli::RawBuffer data_enc;   // setup_wr's worst case, untouched beyond the coded bytes
         std::future<void> done;
+        std::ostringstream log;      // this field's lines, printed when it is written (pipelined mode)
     };
     std::vector<Item> items(job.nf);
+    auto scan = [](const Item& im, std::ostream& os) {
+        const size_t ntot = im.h.spec.count();
+        os << "  read: fld_1d[0]=" << im.fld[0] << " fld_1d[last]=" << im.fld[ntot - 1] << endl;
+        double lo, hi;
+        wrcli::minmax(im.fld.data(), ntot, &lo, &hi);
+        os << "        min=" << lo << " max=" << hi << endl;
+    };
     auto finish = [&](int it) {  // in field order: wait for the codec, then append to .wrh / .wrb
         Item& im = items[it];
         const wrio::FieldSpec& s = im.h.spec;
+        if (im.done.valid()) im.done.get();
+        cout << im.log.str();
         if (s.icomp) {
-            im.done.get();
             cout << "        tolabs=" << im.h.tolabs << endl;
             wrio::append_field_header(job.header_name, it, im.h, im.h.ntot_enc);
             if (im.h.ntot_enc > 0) wrio::append_bytes(job.out_name, im.data_enc.data(), im.h.ntot_enc);
@@ -287,51 +298,63 @@ int main(int argc, char** argv)
             wrio::append_raw_field(job.out_name, s.nbytes, im.fld.data(), s.count());
         }
         std::vector<double>().swap(im.fld);
-        std::vector<unsigned char>().swap(im.data_enc);
+        im.data_enc.release();
     };
+    wrcli::InFlight gate(depth);      // fields between "read" and "written"
+    std::thread writer;
+    std::exception_ptr writer_error;
+    if (depth > 0)
+        writer = std::thread([&]() {
+            try {
+                for (int it = 0; it < job.nf; it++) { gate.wait_launched(it); finish(it); gate.leave(); }
+            } catch (...) { writer_error = std::current_exception(); gate.abort(); }
+        });
     unsigned char recl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    try {
     for (int it = 0; it < job.nf; it++) {
+        if (depth > 0 && !gate.enter()) break;  // waits while `depth` fields are in flight
         Item& im = items[it];
         const wrio::FieldSpec& s = job.fields[it];
-        cout << "Field number " << it << endl;
-        cout << "  contains " << s.nbytes << "-byte floating point data" << endl;
-        cout << "  nx=" << s.nx << "  ny=" << s.ny << "  nz=" << s.nz << "  nh=" << s.nh;
-        if (s.idinv) cout << " and reordering" << endl; else cout << endl;
-        const size_t ntot = s.count();
+        std::ostream& os = depth > 0 ? static_cast<std::ostream&>(im.log) : cout;
+        os << "Field number " << it << endl;
+        os << "  contains " << s.nbytes << "-byte floating point data" << endl;
+        os << "  nx=" << s.nx << "  ny=" << s.ny << "  nz=" << s.nz << "  nh=" << s.nh;
+        if (s.idinv) os << " and reordering" << endl; else os << endl;
         wrio::read_field(job.in_name, job.file_type, job.flip != 0, s, recl, &pos, im.fld);
-        cout << "  read: fld_1d[0]=" << im.fld[0] << " fld_1d[last]=" << im.fld[ntot - 1] << endl;
-        double lo = im.fld[0], hi = im.fld[0];
-        for (size_t j = 0; j < ntot; j++) { lo = fmin(lo, im.fld[j]); hi = fmax(hi, im.fld[j]); }
-        cout << "        min=" << lo << " max=" << hi << endl;
+        if (depth == 0) scan(im, cout);
 
         im.h.spec = s;
         for (int j = 0; j < 8; j++) im.h.recl[j] = recl[j];
-        if (depth > 0 && it - depth >= 0) finish(it - depth);  // `depth` fields in flight once this one is launched
         if (s.icomp) {
-            cout << "  Compression enabled with base relative tolerance " << s.tol_base << endl;
             unsigned char nlaymax; unsigned long cap;
             setup_wr(s.nx, s.ny, s.nz * s.nh, &nlaymax, &cap);
-            im.data_enc.resize(cap);
-            Item* ip = &im;
-            auto work = [ip, cutoff]() {
-                const wrio::FieldSpec& sp = ip->h.spec;
-                unsigned char wlev = 0, nlay = 0;
-                double cut = cutoff;
-                // nh > 1 folds into z (gen_enc.cpp:559,596)
-                encoding_wrap(sp.nx, sp.ny, sp.nz * sp.nh, ip->fld.data(), 1, 1, 1, 1, &cut, &ip->h.tolabs, &ip->h.midval,
-                              &ip->h.halfspanval, &wlev, &nlay, &ip->h.ntot_enc, ip->h.deps_vec, ip->h.minval_vec,
-                              ip->h.len_enc_vec, ip->data_enc.data());
-                ip->h.wlev = wlev; ip->h.nlay = nlay;
-            };
-            if (depth > 0) im.done = std::async(std::launch::async, work);
-            else { work(); std::promise<void> p; p.set_value(); im.done = p.get_future(); }
-        } else {
-            cout << "  Compression disabled" << endl;
+            im.data_enc.allocate(cap);
         }
-        if (depth == 0) finish(it);
+        Item* ip = &im;
+        const bool pipelined = depth > 0;
+        auto work = [ip, cutoff, pipelined, &scan]() {
+            const wrio::FieldSpec& sp = ip->h.spec;
+            if (pipelined) scan(*ip, ip->log);
+            if (!sp.icomp) { (pipelined ? static_cast<std::ostream&>(ip->log) : cout) << "  Compression disabled" << endl; return; }
+            (pipelined ? static_cast<std::ostream&>(ip->log) : cout) << "  Compression enabled with base relative tolerance " << sp.tol_base << endl;
+            unsigned char wlev = 0, nlay = 0;
+            double cut = cutoff;
+            // nh > 1 folds into z (gen_enc.cpp:559,596)
+            encoding_wrap(sp.nx, sp.ny, sp.nz * sp.nh, ip->fld.data(), 1, 1, 1, 1, &cut, &ip->h.tolabs, &ip->h.midval,
+                          &ip->h.halfspanval, &wlev, &nlay, &ip->h.ntot_enc, ip->h.deps_vec, ip->h.minval_vec,
+                          ip->h.len_enc_vec, ip->data_enc.data());
+            ip->h.wlev = wlev; ip->h.nlay = nlay;
+        };
+        if (depth > 0) { im.done = std::async(std::launch::async, work); gate.launched(it); }
+        else { work(); finish(it); }
     }
-    if (depth > 0)
-        for (int it = std::max(0, job.nf - depth); it < job.nf; it++) finish(it);
+    } catch (...) {
+        gate.abort();
+        if (writer.joinable()) writer.join();
+        throw;
+    }
+    if (writer.joinable()) writer.join();
+    if (writer_error) std::rethrow_exception(writer_error);
     cout << "=== End of compression ===\n";
     return 0;
 }

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/mman.h>
 
 #include <atomic>
@@ -590,16 +591,18 @@ void transform_need(int nx, int ny, int nz, int lvl, SlotNeed* need)
 
 // Forward (lvl > 0) or inverse (lvl < 0) transform of d_fld.  The fused path is out of place: the result
 // lands in the slot's scratch buffer and *out points there; the general path works in place.
-void run_transform(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int lvl, double** out)
+int run_transform(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int lvl, double** out)
 {
     *out = d_fld;
     if (use_fused(nx, ny, nz, lvl)) {
+        if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
         if (lvl > 0) wrk::transform_fwd_fused(d_fld, s->scratch, s->lowbuf, nx, ny, nz, c->stream);
         else wrk::transform_inv_fused(d_fld, s->scratch, s->lowbuf, nx, ny, nz, c->stream);
         *out = s->scratch;
     } else {
         wrk::transform(d_fld, s->scratch, nx, ny, nz, lvl, c->stream);
     }
+    return WR_OK;
 }
 
 // decoder back end: acc = sum of planes, then the inverse transform, result in d_fld.
@@ -609,6 +612,7 @@ int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int n
 {
     const size_t n = (size_t)nx * ny * nz;
     const bool fused = wlev == 4 && use_fused(nx, ny, nz, -4);
+    if (fused) if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
     wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
@@ -895,6 +899,19 @@ int wr_host_free(void* ptr)
     return WR_OK;
 }
 
+int wr_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(WR_ERR_ARG, "wr_host_register: empty range");
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return WR_OK;
+}
+
+int wr_host_unregister(void* ptr)
+{
+    HIPCHK(hipHostUnregister(ptr));
+    return WR_OK;
+}
+
 int wr_dev_upload(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;
@@ -964,7 +981,7 @@ int wr_dev_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl)
     if (int rc = slot.acquire(c, need)) return rc;
     StageLock cu(c->pool->cu_mu);
     double* res = nullptr;
-    run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res);
+    if (int rc = run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res)) return rc;
     if (res != d_fld)
         HIPCHK(hipMemcpyAsync(d_fld, res, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipGetLastError());
@@ -1059,6 +1076,7 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
     // before it is known whether the field is trivial; it is out of place, so nothing is lost if it is.
     const size_t mm_records = (wtflag && use_fused(nx, ny, nz, kWavLvl) && !getenv("WR_NO_FUSED_MINMAX")) ? wrk::fused_minmax_records(nx, ny, nz) : 0;
     if (mm_records) {
+        if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
         if (c->mm_records < mm_records) {
             if (c->d_mm) HIPCHK(hipFree(c->d_mm));
             c->d_mm = nullptr; c->mm_records = 0;
@@ -1103,7 +1121,7 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         return WR_OK;
     }
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    run_transform(c, slot, d_fld, nx, ny, nz, (int)info->wlev, &d_fld);  // d_fld := coefficients
+    if (int rc = run_transform(c, slot, d_fld, nx, ny, nz, (int)info->wlev, &d_fld)) return rc;  // d_fld := coefficients
     *resid = d_fld;
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     if (verbose()) printf("Range encoding...\n");
@@ -1247,6 +1265,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     if (!fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
     if (cut.mx < 1 || cut.my < 1 || cut.mz < 1 || !cut.vec) return fail(WR_ERR_ARG, "bad local cutoff description");
     std::lock_guard<std::mutex> lk(c->mu);
+    if (tm) wrdma::enable_timing();
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
     wr_timings local; memset(&local, 0, sizeof local);
@@ -1273,7 +1292,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     const bool per_plane = !pooled && encoder_threads() >= WR_NLAYMAX;
     wrrc::PlaneJob jobs[WR_NLAYMAX];
     wrrc::JobBatch batch;
-    unsigned jobs_submitted = 0;
+    unsigned pool_mask = 0;  // planes the pool took
     auto code_group = [&](unsigned l0, unsigned l1) {
         (void)hipSetDevice(dev);
         for (unsigned l = l0; l < l1; l++)
@@ -1356,8 +1375,8 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
                 wrrc::PlaneJob& j = jobs[l];
                 j.kind = wrrc::PlaneJob::kEncode;
                 j.src = nullptr; j.io = &c->ps[l].io; j.dst = c->enc_buf[l]; j.n = n; j.hist = c->h_hist + l * hist_per_plane;
-                wrrc::pool_submit(&j, 1, &batch);
-                jobs_submitted = l + 1;
+                if (wrrc::pool_submit(&j, 1, &batch)) pool_mask |= 1u << l;
+                else workers.v.emplace_back(code_group, l, l + 1);  // the pool was stopped meanwhile: a thread of this call codes the plane
             }
         }
         t_gpu_done = now();
@@ -1369,7 +1388,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     }
     if (pooled) {
         wrrc::pool_wait(&batch);
-        for (unsigned l = 0; l < jobs_submitted; l++) { lens[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
+        for (unsigned l = 0; l < WR_NLAYMAX; l++) if (pool_mask >> l & 1) { lens[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
     } else if (rc == WR_OK && !per_plane && info->nlay) {
         try {
             const unsigned groups = std::min<unsigned>(info->nlay, (unsigned)encoder_threads());
@@ -1433,13 +1452,19 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
 {
     if (int rc = ctx_bind(c)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (tm) wrdma::enable_timing();
     if (mode == kDecodeFinish) {
         if (!c->pend_valid) return fail(WR_ERR_ARG, "wr_decode_finish without a wr_decode_begin on this context");
         info = &c->pend_info; nx = c->pend_nx; ny = c->pend_ny; nz = c->pend_nz;
-        c->pend_valid = false;
     }
+    // (a finish that is refused for its arguments leaves the begin pending: the caller may try again with a usable
+    // pointer, and the parked planes are not orphaned)
     if (int rc = check_dims(nx, ny, nz, fld.dev)) return rc;
     if (mode != kDecodeBegin && !fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
+    if (mode == kDecodeFinish) c->pend_valid = false;
+    // From here on the context's device planes go back on every way out, unless a begin parks them (a finish finds the
+    // planes its begin parked; a begin or a whole decode discards what an earlier begin left).
+    PlaneHold planes(c);
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
     wr_timings local; memset(&local, 0, sizeof local);
@@ -1464,7 +1489,6 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     if (off[nlay] > info->ntot_enc) return fail(WR_ERR_STREAM, "len_enc_vec exceeds ntot_enc");
     if (host_half && data_len && info->ntot_enc > data_len) return fail(WR_ERR_STREAM, "ntot_enc exceeds the length of the coded buffer");
 
-    PlaneHold planes(c);  // a finish finds the planes its begin parked in the context
     if (host_half) {
         c->pend_valid = false;  // whatever an earlier begin parked here is overwritten now
         for (int l = 0; l < nlay; l++) if (int rc = plane_prepare(c, l, n, true)) return rc;
@@ -1481,8 +1505,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     Sem sem(coder_threads());
     // one thread per plane, or (wr_set_threads) fewer threads with their planes interleaved, or the process-wide
     // coder pool (wr_set_coder_pool), whose workers interleave planes of several fields
-    const bool pooled = wrrc::pool_threads() > 0;
-    const int groups = (pooled || !host_half) ? 0 : std::min(nlay, coder_threads());
+    bool pooled = wrrc::pool_threads() > 0;
     int rc = WR_OK;
     double t_phase = 0, t_coded = t0;
     try {
@@ -1494,10 +1517,13 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
                 jobs[l].kind = wrrc::PlaneJob::kDecode;
                 jobs[l].src = data_enc + off[l]; jobs[l].src_len = info->len_enc_vec[l]; jobs[l].dst = nullptr; jobs[l].io = &c->ps[l].io; jobs[l].n = n;
             }
-            wrrc::pool_submit(jobs, nlay, &batch);
-            wrrc::pool_wait(&batch);
-            for (int l = 0; l < nlay; l++) { got[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
+            if (wrrc::pool_submit(jobs, nlay, &batch)) {
+                wrrc::pool_wait(&batch);
+                for (int l = 0; l < nlay; l++) { got[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
+            } else
+                pooled = false;  // the pool was stopped meanwhile: this call's own threads decode the planes
         }
+        const int groups = (pooled || !host_half) ? 0 : std::min(nlay, coder_threads());
         // Every decoded window of a plane goes to the plane's device buffer while the decoder fills the next one
         // (chunk by chunk: wrappers.cpp:492-516 reorganised); the accumulate kernel consumes the
         // planes in plane order afterwards.
@@ -1668,7 +1694,7 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
     double* res = nullptr;
     {
         StageLock cu(pool->cu_mu);
-        run_transform(c, slot.get(), slot->field, nx, ny, nz, lvl, &res);
+        if (int rc = run_transform(c, slot.get(), slot->field, nx, ny, nz, lvl, &res)) return rc;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
     }
@@ -1709,7 +1735,7 @@ int wr_range_encode_pool(int count, const unsigned char* const* sym, const size_
     std::vector<wrrc::PlaneJob> jobs((size_t)count);
     wrrc::JobBatch batch;
     for (int k = 0; k < count; k++) { jobs[k].kind = wrrc::PlaneJob::kEncode; jobs[k].src = sym[k]; jobs[k].n = n[k]; jobs[k].dst = out[k]; }
-    wrrc::pool_submit(jobs.data(), count, &batch);
+    if (!wrrc::pool_submit(jobs.data(), count, &batch)) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
     wrrc::pool_wait(&batch);
     for (int k = 0; k < count; k++) lens[k] = jobs[k].result;
     return WR_OK;
@@ -1725,7 +1751,7 @@ int wr_range_decode_pool(int count, const unsigned char* const* in, const size_t
     for (int k = 0; k < count; k++) {
         jobs[k].kind = wrrc::PlaneJob::kDecode; jobs[k].src = in[k]; jobs[k].src_len = len[k]; jobs[k].dst = sym[k]; jobs[k].n = n[k];
     }
-    wrrc::pool_submit(jobs.data(), count, &batch);
+    if (!wrrc::pool_submit(jobs.data(), count, &batch)) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
     wrrc::pool_wait(&batch);
     for (int k = 0; k < count; k++) produced[k] = jobs[k].result;
     return WR_OK;
@@ -1791,7 +1817,7 @@ int wr_range_encode_windowed(int mode, int count, const unsigned char* const* sy
         std::vector<wrrc::PlaneJob> jobs((size_t)count);
         wrrc::JobBatch batch;
         for (int k = 0; k < count; k++) { jobs[k].kind = wrrc::PlaneJob::kEncode; jobs[k].n = n; jobs[k].dst = out[k]; jobs[k].io = io[k]; }
-        wrrc::pool_submit(jobs.data(), count, &batch);
+        if (!wrrc::pool_submit(jobs.data(), count, &batch)) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
         wrrc::pool_wait(&batch);
         for (int k = 0; k < count; k++) lens[k] = jobs[k].result;
     }
@@ -1817,11 +1843,76 @@ int wr_range_decode_windowed(int mode, int count, const unsigned char* const* in
         for (int k = 0; k < count; k++) {
             jobs[k].kind = wrrc::PlaneJob::kDecode; jobs[k].src = in[k]; jobs[k].src_len = len[k]; jobs[k].n = n; jobs[k].io = io[k];
         }
-        wrrc::pool_submit(jobs.data(), count, &batch);
+        if (!wrrc::pool_submit(jobs.data(), count, &batch)) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
         wrrc::pool_wait(&batch);
         for (int k = 0; k < count; k++) produced[k] = jobs[k].result;
     }
     return WR_OK;
+}
+
+namespace {
+// CPUs this process may use: its affinity mask, cut down to a cgroup CPU quota if there is one
+int usable_cpus()
+{
+    cpu_set_t set;
+    int n = 0;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = (int)std::thread::hardware_concurrency();
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "max 100000" or "<quota> <period>"
+        char q[64]; double period = 0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const int k = (int)(atof(q) / period + 0.5);
+            if (k >= 1 && k < n) n = k;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
+
+size_t host_mem_available()
+{
+    size_t avail = 0;
+    if (FILE* f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f))
+            if (strncmp(line, "MemAvailable:", 13) == 0) { avail = (size_t)strtoull(line + 13, nullptr, 10) * 1024; break; }
+        fclose(f);
+    }
+    if (FILE* f = fopen("/sys/fs/cgroup/memory.max", "r")) {
+        char q[64];
+        if (fscanf(f, "%63s", q) == 1 && strcmp(q, "max") != 0) {
+            const size_t lim = (size_t)strtoull(q, nullptr, 10);
+            if (lim && (!avail || lim < avail)) avail = lim;
+        }
+        fclose(f);
+    }
+    return avail;
+}
+}  // namespace
+
+int wr_autotune_batch(size_t field_elems, int nfields)
+{
+    if (nfields < 1) nfields = 1;
+    const int cpus = usable_cpus();
+    if (nfields > 1 && cpus >= 2) wr_set_coder_pool(cpus, 0);
+    // 1.5 fields in flight per CPU keep the pool's workers busy (a field spends part of its time in copies, kernels and
+    // waiting for its slowest plane)
+    long fit = (3L * cpus + 1) / 2;
+    const double fb = 8.0 * (double)(field_elems ? field_elems : 1);
+    // host: the caller's field and coded buffers plus the coder's output while it is produced: ~2.5 field sizes per call
+    if (const size_t mem = host_mem_available()) { const long k = (long)(0.6 * (double)mem / (2.5 * fb)); if (k < fit) fit = k; }
+    // device: three work-space slots of 2.2 field sizes; per call its quantized planes (1 byte per element and plane, 4-5
+    // planes at the usual tolerances, 8 at most)
+    int dev = 0;
+    if (const char* e = getenv("WR_DEVICE")) dev = atoi(e);
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const long k = (long)((0.9 * (double)free_b - 3 * 2.2 * fb) / (0.75 * fb));
+        if (k < fit) fit = k;
+    } else
+        (void)hipGetLastError();
+    if (fit > nfields) fit = nfields;
+    return fit < 1 ? 1 : (int)fit;
 }
 
 int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl, int reps, double* ms_out)
@@ -1836,7 +1927,8 @@ int wr_bench_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl
     StageLock cu(c->pool->cu_mu);
     double* res = nullptr;
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    for (int r = 0; r < reps; r++) run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res);  // fused: result stays in scratch
+    for (int r = 0; r < reps; r++)
+        if (int rc = run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res)) return rc;  // fused: result stays in scratch
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventSynchronize(c->ev_b));

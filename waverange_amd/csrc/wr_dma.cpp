@@ -13,6 +13,8 @@ namespace {
 std::once_flag g_once;
 bool g_ok = false;
 double g_ticks_per_ms = 0;
+std::once_flag g_timing_once;
+bool g_timing = false;
 
 void init()
 {
@@ -21,17 +23,20 @@ void init()
     uint64_t freq = 0;
     if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq) == HSA_STATUS_SUCCESS && freq)
         g_ticks_per_ms = (double)freq / 1e3;
-    (void)hsa_amd_profiling_async_copy_enable(true);  // engine timestamps on the completion signals
     g_ok = true;
 }
 
-// owner agent of an allocation ROCr knows; false for anything else (pageable host memory)
+// owner agent of an allocation ROCr made (device memory, hipHostMalloc); false for anything else.  Pageable host
+// memory is unknown to ROCr.  Memory the caller pinned with hipHostRegister (HSA_EXT_POINTER_TYPE_LOCKED) is known, but
+// the address the GPU sees it at is agentBaseAddress + offset, not the host address: hsa_amd_memory_async_copy does not
+// translate, HIP's own memcpy does -- so such buffers take the hipMemcpyAsync path like pageable ones (they still move
+// by DMA there, without the runtime's staging copy).
 bool owner_of(const void* p, hsa_agent_t* agent)
 {
     hsa_amd_pointer_info_t info;
     info.size = sizeof info;
     if (hsa_amd_pointer_info(const_cast<void*>(p), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return false;
-    if (info.type != HSA_EXT_POINTER_TYPE_HSA && info.type != HSA_EXT_POINTER_TYPE_LOCKED) return false;
+    if (info.type != HSA_EXT_POINTER_TYPE_HSA) return false;
     *agent = info.agentOwner;
     return true;
 }
@@ -96,9 +101,17 @@ int wait(Signal s)
     }
 }
 
+void enable_timing()
+{
+    if (!available()) return;
+    // engine timestamps on the completion signals: a process-wide ROCr switch, so only thrown when a caller asks for
+    // timings (wr_timings), and never back (other copies may be in flight)
+    std::call_once(g_timing_once, [] { g_timing = hsa_amd_profiling_async_copy_enable(true) == HSA_STATUS_SUCCESS; });
+}
+
 double last_copy_ms(Signal s)
 {
-    if (!g_ticks_per_ms) return -1;
+    if (!g_ticks_per_ms || !g_timing) return -1;
     hsa_signal_t h; h.handle = s;
     hsa_amd_profiling_async_copy_time_t t;
     if (hsa_amd_profiling_get_async_copy_time(h, &t) != HSA_STATUS_SUCCESS) return -1;

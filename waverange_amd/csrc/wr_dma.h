@@ -21,18 +21,22 @@ Signal signal_create();            // 0 on failure
 void signal_destroy(Signal s);
 // Arms `s` for `count` copies that will name it as their completion signal.
 void signal_arm(Signal s, int count);
-// dst / src are a (device, ROCr-known host) pair, i.e. copy_async will take them
+// dst / src are a (device memory, hipHostMalloc'd host memory) pair, i.e. copy_async will take them.  Pageable memory
+// and memory pinned by the caller with hipHostRegister are refused: the caller sends them through hipMemcpyAsync.
 bool can_copy(const void* dst, const void* src);
 // Takes `count` copies that were armed but never started off the signal again (error paths).
 void signal_cancel(Signal s, int count);
 // Starts an asynchronous copy of `bytes` from src to dst; exactly one of them is device memory, the other
-// host memory known to ROCr (hipHostMalloc / hipHostRegister).  Returns 0 when queued on a DMA engine,
-// 1 when the host pointer is ordinary pageable memory (the caller then falls back to hipMemcpyAsync),
+// host memory allocated by ROCr (hipHostMalloc / wr_host_alloc).  Returns 0 when queued on a DMA engine,
+// 1 when the host pointer is pageable or hipHostRegister'd memory (the caller then falls back to hipMemcpyAsync),
 // -1 on error.  `s` is decremented when the copy has finished.
 int copy_async(void* dst, const void* src, size_t bytes, Signal s);
 // Blocks (without spinning) until every copy armed on `s` has finished.  Returns 0, or -1 if a copy failed.
 int wait(Signal s);
-// Duration of the last copy that completed on `s`, in milliseconds (engine timestamps); < 0 if unknown.
+// Engine timestamps for last_copy_ms: off until someone asks (a process-wide ROCr profiling switch).
+void enable_timing();
+// Duration of the last copy that completed on `s`, in milliseconds (engine timestamps); < 0 if unknown
+// (enable_timing not called before the copy started).
 double last_copy_ms(Signal s);
 
 }  // namespace wrdma

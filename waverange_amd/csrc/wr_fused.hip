@@ -693,17 +693,39 @@ __global__ __launch_bounds__(256) void k_minmax_final4(const double* __restrict_
     }
 }
 
+// The fused kernels need more dynamic LDS than a kernel gets by default: raised once per process, and the one call whose
+// failure would make every later launch fail with "invalid argument" is checked here, where the cause is still known.
+const char* fused_prepare()
+{
+    static std::once_flag once;
+    static char msg[256];
+    static bool failed = false;
+    std::call_once(once, [] {
+        struct { const void* fn; const char* name; int bytes; } ks[] = {
+            {(const void*)k_fwd_fused<false, false>, "k_fwd_fused<false,false>", (int)LDS_BYTES},
+            {(const void*)k_fwd_fused<true, true>, "k_fwd_fused<true,true>", (int)LDS_BYTES},
+            {(const void*)k_fwd_fused<false, true>, "k_fwd_fused<false,true>", (int)LDS_BYTES},
+            {(const void*)k_inv_fused, "k_inv_fused", (int)LDS_INV}};
+        for (const auto& k : ks) {
+            const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                snprintf(msg, sizeof msg, "fused transform: %s cannot have %d bytes of dynamic LDS (%s); this build is for gfx950 (160 KB of LDS per CU)",
+                         k.name, k.bytes, hipGetErrorString(e));
+                failed = true;
+                return;
+            }
+        }
+    });
+    return failed ? msg : nullptr;
+}
+
 // mm_partial != nullptr (needs fused_minmax_records() > 0): min/max of the field and of the coefficient array
 // are reduced on the way and land in mm_result[0..3].
 void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st,
                          double* mm_partial, double* mm_result)
 {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)k_fwd_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)k_fwd_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)k_fwd_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    });
+    (void)fused_prepare();  // (callers check it before they choose this path: wr_api.cpp)
     const size_t d_sy = (size_t)nx, d_sz = (size_t)nx * ny;
     const int nfused = fused_levels(nx, ny, nz, false);
     const bool mm = mm_partial != nullptr && nfused == 4;
@@ -752,8 +774,7 @@ void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int n
 
 void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
-    static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_inv_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV); });
+    (void)fused_prepare();
     const size_t f_sy = (size_t)nx, f_sz = (size_t)nx * ny;
     const int nfused = fused_levels(nx, ny, nz, true);
     // compact reconstruction buffers: C1 = (n/2)^3, C2 = (n/4)^3, C3 = (n/8)^3, laid out as in the forward pass

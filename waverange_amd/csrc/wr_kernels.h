@@ -80,6 +80,8 @@ namespace wrk {
 int fused_levels(int nx, int ny, int nz, bool inverse);
 bool fused_ok(int nx, int ny, int nz, int lvl);
 size_t fused_lowbuf_elems(int nx, int ny, int nz);
+// one-time set-up of the fused kernels (their dynamic LDS limit); nullptr, or why they cannot run on this device
+const char* fused_prepare();
 // mm_partial (fused_minmax_records() x 4 doubles, device) and mm_result (4 doubles, device): when given -- and all
 // four levels run fused -- the forward kernels also reduce min/max of the field read and of the coefficient array
 // written; mm_result = {field min, field max, coefficient min, coefficient max} (NaNs skipped, the sign of a zero

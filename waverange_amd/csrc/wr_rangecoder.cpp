@@ -25,6 +25,17 @@
 
 namespace wrrc {
 
+// CPU dispatch for the AVX-512 loops.  Lives here, not next to them: wr_rangecoder_avx512.cpp is built with
+// -mavx512*, so the compiler may use those instructions anywhere in that file -- also in a function whose job is to
+// find out whether the CPU has them.
+bool vec_available()
+{
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
+                           !(getenv("WR_NO_AVX512") && atoi(getenv("WR_NO_AVX512")));
+    return ok;
+}
+
 namespace {
 
 constexpr uint32_t kTop = 0x80000000u;     // rangecod.c:121  1 << (CODE_BITS-1)
@@ -806,6 +817,30 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
 
 namespace {
 
+// Slow-path block of one stream (partial block, window or stream about to end): decoded straight into what is left
+// of the stream's window, or -- a block that straddles the end of a window although the plane goes on, which only
+// happens behind a block of fewer than 60000 symbols in mid-stream: the reference's encoder never writes one, the
+// format allows it -- into a bounce buffer whose parts go to this window and the following one(s).
+inline void decode_block_checked(Dec& d, const BlockModel& m, SymCursor& cur, uint8_t* dst, size_t at, size_t n, std::vector<uint8_t>& bounce)
+{
+    if (!m.bs) return;
+    const size_t room = cur.room(at);  // symbols beyond it are dropped (a stream that holds more than the plane has)
+    const bool split = room < m.bs && at + room < n;
+    if (split) { if (bounce.size() < kBlock) bounce.resize(kBlock); dst = bounce.data(); }
+    if (m.bs == kBlock) decode_symbols<kBlock>(d, dst, split ? m.bs : room, m.bs, m.tab, m.lookup, m.top);
+    else decode_symbols<0>(d, dst, split ? m.bs : room, m.bs, m.tab, m.lookup, m.top);
+    if (!split) return;
+    size_t done = 0;
+    while (done < m.bs && at + done < n) {
+        uint8_t* const w = cur.at(at + done, n);  // moves the window on when `at + done` has run out of it
+        size_t r = cur.room(at + done);
+        if (r > m.bs - done) r = m.bs - done;
+        if (!r) break;
+        memcpy(w, bounce.data() + done, r);
+        done += r;
+    }
+}
+
 // A set of up to kMaxDecStreams plane streams advancing block by block in lockstep on one thread
 // (wrappers.cpp:153-224 per stream).  Streams join at any block boundary and leave when they end.
 class DecGroup {
@@ -871,9 +906,7 @@ public:
         }
         for (int k = 0; k < count_;) {
             const BlockModel& m = *ms_[k];
-            const size_t room = cur_[k].room(produced_[k] < n_[k] ? produced_[k] : n_[k]);  // symbols beyond it are dropped
-            if (m.bs == kBlock) decode_symbols<kBlock>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
-            else if (m.bs) decode_symbols<0>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
+            decode_block_checked(*ds_[k], m, cur_[k], dst_[k], produced_[k] < n_[k] ? produced_[k] : n_[k], n_[k], bounce_);
             produced_[k] += m.bs;
             if (ds_[k]->pos > ds_[k]->len + 8) { failed_[k] = true; retire(k, on_end); continue; }  // ran far past the end: corrupt stream
             k++;
@@ -909,6 +942,7 @@ private:
     bool failed_[kMaxDecStreams];
     void* tag_[kMaxDecStreams];
     std::vector<uint8_t> tails_[kMaxDecStreams];
+    std::vector<uint8_t> bounce_;  // decode_block_checked
 };
 
 }  // namespace
@@ -1009,9 +1043,7 @@ public:
             if (vec[k]) { k++; continue; }
             BlockModel& m = *ms_[k];
             if (!m.tables_ready) finish_model_tables(m);
-            const size_t room = cur_[k].room(produced_[k] < n_[k] ? produced_[k] : n_[k]);
-            if (m.bs == kBlock) decode_symbols<kBlock>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
-            else if (m.bs) decode_symbols<0>(*ds_[k], dst_[k], room, m.bs, m.tab, m.lookup, m.top);
+            decode_block_checked(*ds_[k], m, cur_[k], dst_[k], produced_[k] < n_[k] ? produced_[k] : n_[k], n_[k], bounce_);
             produced_[k] += m.bs;
             if (ds_[k]->pos > ds_[k]->len + 8) {
                 failed_[k] = true;
@@ -1052,6 +1084,7 @@ private:
     bool failed_[kCap];
     void* tag_[kCap];
     std::vector<uint8_t> tails_[kCap];
+    std::vector<uint8_t> bounce_;  // decode_block_checked
 };
 
 }  // namespace
@@ -1129,9 +1162,12 @@ public:
         stop_ = false;
         for (int i = 0; i < nthreads; i++) workers_.emplace_back([this] { run(); });
     }
-    void submit(PlaneJob* jobs, int count, JobBatch* batch)
+    // false: the pool has no workers (never started, or stopped meanwhile by another thread) -- nothing was queued and
+    // the caller codes the planes itself
+    bool submit(PlaneJob* jobs, int count, JobBatch* batch)
     {
         std::lock_guard<std::mutex> lk(mu_);
+        if (workers_.empty()) return false;
         for (int i = 0; i < count; i++) {
             jobs[i].batch = batch;
             // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
@@ -1144,6 +1180,7 @@ public:
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
         if (count > 1) cv_.notify_all(); else cv_.notify_one();
+        return true;
     }
     ~Pool() { resize(0, 0); }
 
@@ -1309,7 +1346,7 @@ void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
 void pool_loop_stats(double seconds[4], double blocks[4]) { Pool::get().loop_stats(seconds, blocks); }
-void pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { Pool::get().submit(jobs, count, batch); }
+bool pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { return Pool::get().submit(jobs, count, batch); }
 void pool_wait(JobBatch* batch)
 {
     std::unique_lock<std::mutex> lk(batch->mu);

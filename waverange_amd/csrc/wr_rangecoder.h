@@ -88,7 +88,9 @@ void pool_configure(int nthreads, int dec_streams);  // nthreads = 0 stops the p
 int pool_threads();
 void pool_loop_stats(double seconds[4], double blocks[4]);  // per loop kind {scalar enc, scalar dec, vector dec, vector enc}: worker seconds in block steps, stream-blocks advanced
 double pool_idle_seconds();  // time the workers have spent waiting for a job since the process started, summed over workers
-void pool_submit(PlaneJob* jobs, int count, JobBatch* batch);  // the jobs must stay valid until pool_wait returns
+// The jobs must stay valid until pool_wait returns.  False (nothing queued) if the pool has no workers -- it may have
+// been stopped by another thread since the caller looked at pool_threads(): the caller then codes the planes itself.
+bool pool_submit(PlaneJob* jobs, int count, JobBatch* batch);
 void pool_wait(JobBatch* batch);
 
 }  // namespace wrrc

@@ -1,5 +1,6 @@
 // wr_rangecoder_avx512.cpp -- see wr_rangecoder_vec.h.  Compiled with -mavx512f -mavx512bw -mavx512dq -mavx512vl;
-// entered only when vec_available().
+// entered only when vec_available() (wr_rangecoder.cpp: the dispatcher is built without those flags).  Nothing but
+// the block kernels lives here.
 #include "wr_rangecoder_vec.h"
 
 #include <immintrin.h>
@@ -26,14 +27,6 @@ inline void transpose16x16(__m128i r[16])
 }
 
 }  // namespace
-
-bool vec_available()
-{
-    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
-                           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl") &&
-                           !(getenv("WR_NO_AVX512") && atoi(getenv("WR_NO_AVX512")));
-    return ok;
-}
 
 void vec_decode_block(VecBlock* b, VecOther other)
 {
