@@ -1,6 +1,7 @@
 // wrdec (FluSI) -- HDF5 front-end of the decoder, reference src/flusi/main_dec.cpp.
 //   wrdec compressed_000.h5 decompressed_000.h5 TYPE PRECISION   PRECISION 1: single, 2: double
 #include <cmath>
+#include <memory>
 
 #include "flusi_common.h"
 #include "flusi_h5.h"
@@ -18,7 +19,10 @@ struct Item {
     double time = 0, nu = 0, epsi = 0, domain[3] = {0, 0, 0};
     int nxyz[3] = {0, 0, 0};
     std::vector<unsigned char> data;
-    std::vector<double> rec;
+    std::unique_ptr<double[]> rec;   // not zero-filled: the decoder writes every element
+    size_t n = 0;
+    double lo = 0, hi = 0;
+    flusi::Phases ph;
     wr_enc_info info;
     std::future<int> done;
 };
@@ -57,16 +61,15 @@ int main(int argc, char** argv)
             if (flusi::has_dataset(in_name, n)) names.push_back(n);
     }
     flusi::Pipeline pipe;
-    if (!pipe.open()) return 1;
+    flusi::Clock clk;
     std::vector<Item> items(names.size());
     auto finish = [&](Item& it) {
-        if (it.done.get() != WR_OK) { std::cerr << "wrdec: " << it.name << ": " << wr_last_error() << endl; exit(1); }
-        const size_t n = it.rec.size();
+        if (it.done.get() != WR_OK) { std::cerr << "wrdec: " << it.name << ": decode failed" << endl; exit(1); }
+        it.ph.write0 = clk.now();
+        const size_t n = it.n;
         cout << "  decode: fld_1d_rec[0]=" << it.rec[0] << " fld_1d_rec[last]=" << it.rec[n - 1] << endl;
-        double lo = it.rec[0], hi = it.rec[0];
-        for (size_t j = 0; j < n; j++) { lo = fmin(lo, it.rec[j]); hi = fmax(hi, it.rec[j]); }
-        cout << "        min=" << lo << " max=" << hi << endl;
-        flusi::write_field(out_name, it.name, it.rec.data(), it.nx, it.ny, it.nz, outtype == 1);
+        cout << "        min=" << it.lo << " max=" << it.hi << endl;
+        flusi::write_field(out_name, it.name, it.rec.get(), it.nx, it.ny, it.nz, outtype == 1);
         if (it.backup) flusi::write_attr_double(out_name, it.name, "bckp", it.bckp, 8);
         else {
             flusi::write_attr_double(out_name, it.name, "time", &it.time, 1);
@@ -75,8 +78,11 @@ int main(int argc, char** argv)
             flusi::write_attr_double(out_name, it.name, "domain_size", it.domain, 3);
             flusi::write_attr_int(out_name, it.name, "nxyz", it.nxyz, 3);
         }
-        std::vector<double>().swap(it.rec);
+        it.rec.reset();
+        it.ph.write1 = clk.now();
+        if (clk.on) it.ph.print(it.name);
     };
+    size_t next_to_finish = 0;
     for (size_t k = 0; k < items.size(); k++) {
         Item& it = items[k];
         it.name = names[k];
@@ -94,20 +100,27 @@ int main(int argc, char** argv)
             it.nx = it.nxyz[0]; it.ny = it.nxyz[1]; it.nz = it.nxyz[2];
         }
         cout << " dset=" << it.name << " nx=" << it.nx << " ny=" << it.ny << " nz=" << it.nz << endl;
-        flusi::read_coded(in_name, it.name, it.data, it.info);
         const size_t n = (size_t)it.nx * it.ny * it.nz;
-        const int slot = (int)(k & 1);
-        if (k >= 2) finish(items[k - 2]);
-        it.rec.resize(n);
-        wr_ctx* c = pipe.ctx[slot];
+        if (k == 0 && !pipe.open(n, (int)items.size())) return 1;
+        if (k - next_to_finish >= (size_t)pipe.depth()) finish(items[next_to_finish++]);
+        it.ph.read0 = clk.now();
+        flusi::read_coded(in_name, it.name, it.data, it.info);
+        it.ph.read1 = clk.now();
+        it.n = n;
+        it.rec.reset(new double[n]);
+        wr_ctx* c = pipe.ctx[k % pipe.depth()];
         Item* ip = &it;
-        it.done = std::async(std::launch::async, [c, ip]() {
-            const int rc = wr_decode_host(c, ip->rec.data(), ip->nx, ip->ny, ip->nz, &ip->info, ip->data.data(), ip->data.size(), nullptr);
+        const flusi::Clock* ck = &clk;
+        it.done = std::async(std::launch::async, [c, ip, ck]() {
+            ip->ph.call0 = ck->now();
+            const int rc = wr_decode_host(c, ip->rec.get(), ip->nx, ip->ny, ip->nz, &ip->info, ip->data.data(), ip->data.size(), &ip->ph.tm);
+            ip->ph.call1 = ck->now();
             std::vector<unsigned char>().swap(ip->data);
+            if (rc == WR_OK) flusi::minmax(ip->rec.get(), ip->n, &ip->lo, &ip->hi);
             return rc;
         });
     }
-    for (size_t k = items.size() >= 2 ? items.size() - 2 : 0; k < items.size(); k++) finish(items[k]);
+    while (next_to_finish < items.size()) finish(items[next_to_finish++]);
     cout << "=== End of decompression ===\n";
     return 0;
 }

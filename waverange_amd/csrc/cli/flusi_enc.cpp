@@ -2,7 +2,8 @@
 //   wrenc original_000.h5 compressed_000.h5 TYPE TOLERANCE     TYPE 0: regular output, 1: backup
 // Regular files hold one dataset with attributes time / viscosity / epsi / domain_size / nxyz;
 // backup files hold up to 50 named datasets with a `bckp` attribute (main_enc.cpp:319-330).
-// Datasets are pipelined over two GPU contexts (BASELINE config 5: overlap across ux, uy, uz).
+// The datasets of a file are in flight together (BASELINE config 5: ux, uy, uz overlap -- dataset k+1's read, upload and
+// transform run under dataset k's range coding; flusi_common.h::Pipeline).
 #include <cmath>
 
 #include "flusi_common.h"
@@ -22,8 +23,10 @@ struct Item {
     double time = 0, nu = 0, epsi = 0, domain[3] = {0, 0, 0};
     int nxyz[3] = {0, 0, 0};
     std::vector<double> fld;
-    std::vector<unsigned char> data;
+    flusi::RawBytes data;
     wr_enc_info info;
+    double lo = 0, hi = 0;
+    flusi::Phases ph;
     std::future<int> done;
 };
 
@@ -64,12 +67,14 @@ int main(int argc, char** argv)
     }
 
     flusi::Pipeline pipe;
-    if (!pipe.open()) return 1;
+    flusi::Clock clk;
     std::vector<Item> items(names.size());
     auto finish = [&](Item& it) {  // in dataset order: wait for the codec, then write (main thread owns HDF5)
         if (it.done.get() != WR_OK) { std::cerr << "wrenc: " << it.name << ": encode failed" << endl; exit(1); }
+        it.ph.write0 = clk.now();
+        cout << " dset=" << it.name << "  min=" << it.lo << " max=" << it.hi << endl;
         cout << "        tolabs=" << it.info.tolabs << endl;
-        flusi::write_coded(out_name, it.name, it.data.data(), it.info);
+        flusi::write_coded(out_name, it.name, it.data.p, it.info);
         if (it.backup) flusi::write_attr_double(out_name, it.name, "bckp", it.bckp, 8);
         else {
             flusi::write_attr_double(out_name, it.name, "time", &it.time, 1);
@@ -78,8 +83,11 @@ int main(int argc, char** argv)
             flusi::write_attr_double(out_name, it.name, "domain_size", it.domain, 3);
             flusi::write_attr_int(out_name, it.name, "nxyz", it.nxyz, 3);
         }
-        std::vector<unsigned char>().swap(it.data);
+        it.data.release();
+        it.ph.write1 = clk.now();
+        if (clk.on) it.ph.print(it.name);
     };
+    size_t next_to_finish = 0;
     for (size_t k = 0; k < items.size(); k++) {
         Item& it = items[k];
         it.name = names[k];
@@ -98,27 +106,30 @@ int main(int argc, char** argv)
         }
         cout << " dset=" << it.name << " nx=" << it.nx << " ny=" << it.ny << " nz=" << it.nz << endl;
         const size_t n = (size_t)it.nx * it.ny * it.nz;
+        if (k == 0 && !pipe.open(n, (int)items.size())) return 1;  // the first dataset sizes the pipeline
+        if (k - next_to_finish >= (size_t)pipe.depth()) finish(items[next_to_finish++]);  // frees the oldest dataset's context
+        it.ph.read0 = clk.now();
         flusi::read_field(in_name, it.name, it.fld, n);
+        it.ph.read1 = clk.now();
         cout << "  read: fld_1d[0]=" << it.fld[0] << " fld_1d[last]=" << it.fld[n - 1] << endl;
-        double lo = it.fld[0], hi = it.fld[0];
-        for (size_t j = 0; j < n; j++) { lo = fmin(lo, it.fld[j]); hi = fmax(hi, it.fld[j]); }
-        cout << "        min=" << lo << " max=" << hi << endl;
-        const int slot = (int)(k & 1);
-        if (k >= 2) finish(items[k - 2]);  // frees this slot's context
         unsigned char nl; unsigned long cap;
         setup_wr(it.nx, it.ny, it.nz, &nl, &cap);
-        it.data.resize(cap);
-        wr_ctx* c = pipe.ctx[slot];
+        if (!it.data.allocate(cap)) { std::cerr << "wrenc: out of memory" << endl; return 1; }
+        wr_ctx* c = pipe.ctx[k % pipe.depth()];
         Item* ip = &it;
-        it.done = std::async(std::launch::async, [c, ip, tol]() {
+        const flusi::Clock* ck = &clk;
+        it.done = std::async(std::launch::async, [c, ip, tol, n, ck]() {
+            flusi::minmax(ip->fld.data(), n, &ip->lo, &ip->hi);
             const double cutoff = tol;
-            const int rc = wr_encode_host(c, ip->fld.data(), ip->nx, ip->ny, ip->nz, 1, 1, 1, 1, &cutoff, &ip->info, ip->data.data(),
-                                          ip->data.size(), nullptr);
+            ip->ph.call0 = ck->now();
+            const int rc = wr_encode_host(c, ip->fld.data(), ip->nx, ip->ny, ip->nz, 1, 1, 1, 1, &cutoff, &ip->info, ip->data.p,
+                                          ip->data.bytes, &ip->ph.tm);
+            ip->ph.call1 = ck->now();
             std::vector<double>().swap(ip->fld);
             return rc;
         });
     }
-    for (size_t k = items.size() >= 2 ? items.size() - 2 : 0; k < items.size(); k++) finish(items[k]);
+    while (next_to_finish < items.size()) finish(items[next_to_finish++]);
     cout << "=== End of compression ===\n";
     return 0;
 }
