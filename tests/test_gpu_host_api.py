@@ -1,7 +1,7 @@
 """Host-buffer entry points (wr_encode_host / wr_decode_host, what the drop-in encoding_wrap / decoding_wrap run
 on) against the oracle; the work-space slots; plane-ordered upload under the range decoder; dimensions beyond
-the launch-grid limits; and the two full-size parity cases of BASELINE.json: 1024^3 (configs[2]) coded bytes
-against the oracle, NF=8 x 512^3 sharded (configs[3]) container against the oracle-coded container.
+the launch-grid limits; and NF=8 x 512^3 sharded (BASELINE configs[3]): container against the oracle-coded container
+(configs[2], 1024^3, lives in tests/test_golden_large.py: against the reference's own outputs).
 Run on the GPU box: python -m pytest tests -m gpu"""
 import os
 import shutil
@@ -182,51 +182,9 @@ def test_dimensions_beyond_the_launch_grid_limits(ctx, oracle, shape):
     assert bits_equal(out, oracle.decode(want, f.shape))
 
 
-def test_full_size_1024_coded_bytes_vs_oracle(ctx, api, oracle):
-    """BASELINE configs[2]: the single 1024^3 fp64 field (seed 12345) at tol 1e-3 and 1e-7.  The oracle encodes the
-    same field on the host cores of this box (one thread per tolerance, a few minutes); plane count, header
-    scalars (bit patterns), plane lengths and the SHA-256 of all coded bytes must agree -- "bit-identical .wrb vs
-    CPU reference" at the headline size.  The GPU reconstruction is then held against the original: within
-    the band the reference's own error control gives."""
-    n = 1024
-    shape = (n, n, n)
-    dbuf = ctx.alloc(n ** 3 * 8)
-    ctx.synth_field(dbuf, n, n, n, 12345)
-    ctx.sync()
-    f = api.pinned_array(shape)
-    api._check(api.lib().wr_dev_download(ctx.h, f.ctypes.data, dbuf.ptr, f.nbytes))
-    dbuf.free()
-    tols = (1e-3, 1e-7)
-    want = {}
-
-    def cpu(tol):
-        e = oracle.encode(f, tol)
-        want[tol] = dict(nlay=e["nlay"], len_enc_vec=e["len_enc_vec"], ntot_enc=e["ntot_enc"], tolabs=e["tolabs"],
-                         midval=e["midval"], halfspanval=e["halfspanval"], deps_vec=e["deps_vec"], minval_vec=e["minval_vec"],
-                         sha=sha(e["data"]))
-
-    ths = [threading.Thread(target=cpu, args=(t,)) for t in tols]
-    for t in ths:
-        t.start()
-    got = {}
-    out = api.pinned_array(shape)
-    for tol in tols:   # the GPU side runs while the oracle threads work
-        enc, _ = ctx.encode_host(f, tol)
-        got[tol] = dict(enc, sha=sha(enc["data"]))
-        ctx.decode_host(out, enc)
-        diff = amax = 0.0
-        for z in range(0, n, 64):
-            diff = max(diff, float(np.abs(f[z:z + 64] - out[z:z + 64]).max()))
-            amax = max(amax, float(np.abs(f[z:z + 64]).max()))
-        assert diff / amax < 1.1 * tol, (tol, diff / amax)   # Q5: the reference itself exceeds tol by a few %
-        del got[tol]["data"]
-    for t in ths:
-        t.join()
-    for tol in tols:
-        g, w = got[tol], want[tol]
-        for k in ("nlay", "len_enc_vec", "ntot_enc", "tolabs", "midval", "halfspanval", "sha"):
-            assert g[k] == w[k], (tol, k, g[k], w[k])
-        assert bits_equal(g["deps_vec"], w["deps_vec"]) and bits_equal(g["minval_vec"], w["minval_vec"]), tol
+# (BASELINE configs[2], the 1024^3 field at tol 1e-3 and 1e-7: tests/test_golden_large.py holds the product against what
+# the reference itself produced at that size -- on per-call coder threads and on the pool / AVX-512 configuration the
+# bench times -- instead of running the oracle on the GPU box for a minute.)
 
 
 def test_config4_sharded_fields_container_vs_oracle(oracle, tmp_path):
