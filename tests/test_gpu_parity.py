@@ -508,3 +508,20 @@ def test_zero_minimum_and_nans_on_the_fused_minmax_path(ctx, oracle, shape):
     buf.free()
     assert enc["nlay"] == want["nlay"] and bits_equal(enc["minval_vec"], want["minval_vec"])
     assert np.array_equal(enc["data"], want["data"])
+
+
+def test_fortran_example_field(ctx, golden):
+    """G7: the reference's Fortran example (examples/fortran/example_fort.f90:82-120: 64^3 field 10 sin x sin^2 y cos z, tolrel
+    1e-6, encode + decode, relative L-inf error) on the GPU path: every output equals the compiled reference's."""
+    from util import g7_field
+    rec = golden["G7_fortran_example_64"]
+    f = g7_field(rec)
+    buf = ctx.to_device(f)
+    enc, _ = ctx.encode(buf, f.shape, rec["tolrel"])
+    enc["data"] = enc["data"].copy()
+    check_enc_record(enc, rec, "G7")
+    ctx.decode(buf, f.shape, enc)
+    dec = buf.download(np.float64, f.size).reshape(f.shape)
+    buf.free()
+    assert sha(dec) == rec["decoded_sha256"]
+    assert np.abs(dec - f).max() / np.abs(f).max() == rec["linf_rel"] < rec["tolrel"]

@@ -117,3 +117,16 @@ def test_minmax_zero_sign_rule(oracle):
     x = np.array([-0.0, 1.0, 0.0, 0.5])
     mn, _ = oracle.minmax(x)
     assert mn == 0 and not np.signbit(mn)
+
+
+def test_g7_fortran_example_field(oracle, golden):
+    """G7: the field of examples/fortran/example_fort.f90:82-91 at its tolrel 1e-6 -- the oracle against
+    what the compiled reference produced, and the relative L-inf error the example would print."""
+    from util import g7_field
+    rec = golden["G7_fortran_example_64"]
+    f = g7_field(rec)
+    e = oracle.encode(f, rec["tolrel"])
+    check_enc_record(e, rec, "G7")
+    dec = oracle.decode(e, f.shape)
+    assert sha(dec) == rec["decoded_sha256"]
+    assert np.abs(dec - f).max() / np.abs(f).max() == rec["linf_rel"] < rec["tolrel"]

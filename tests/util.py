@@ -90,3 +90,13 @@ def check_large_record(e, rec, what=""):
         assert sha_big(data[off:off + n]) == rec["plane_sha256"][l], (what, "coded bytes of plane %d differ from the reference's" % l)
         off += n
     assert sha_big(data) == rec["data_sha256"], what
+
+
+def g7_field(rec):
+    """The reference's Fortran-example field (examples/fortran/example_fort.f90:82-91) rebuilt from the 1-D factors the
+    fixture carries: ((10 sin x) (sin y)^2) cos z, multiplied in the example's order."""
+    sx = np.array([float.fromhex(v) for v in rec["sin_factor"]])
+    cz = np.array([float.fromhex(v) for v in rec["cos_factor"]])
+    f = ((10.0 * sx)[None, None, :] * (sx * sx)[None, :, None]) * cz[:, None, None]
+    assert sha(f) == rec["input_sha256"]
+    return f

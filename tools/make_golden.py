@@ -139,6 +139,30 @@ def main():
                    tolabs=hexf(e["tolabs"]), midval=hexf(e["midval"]),
                    halfspanval=hexf(e["halfspanval"]))
 
+    # G7: the field of the reference's Fortran example (examples/fortran/example_fort.f90:82-91: 10 sin(x) sin(y)^2 cos(z) on
+    # 64^3, tolrel 1e-6), evaluated in C with this container's libm (tools/native/g7_field.c).  The field is a product of
+    # three 1-D factors, so the fixture carries those (192 hex doubles) and the tests rebuild it with IEEE multiplications
+    # in the same order -- no libm on the test side.
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        exe, raw = os.path.join(d, "g7"), os.path.join(d, "g7.raw")
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tools", "native", "g7_field.c"), "-o", exe, "-lm"])
+        subprocess.check_call([exe, "64", "64", "64", raw])
+        g7 = np.fromfile(raw, dtype=np.float64).reshape(64, 64, 64)
+    import math
+    sx = np.array([math.sin(i / 64.0) for i in range(64)])
+    cz = np.array([math.cos(i / 64.0) for i in range(64)])
+    rebuilt = ((10.0 * sx)[None, None, :] * (sx * sx)[None, :, None]) * cz[:, None, None]
+    assert np.array_equal(rebuilt.view(np.uint64), g7.view(np.uint64)), "the factor form does not reproduce the C evaluation"
+    e = ref.encode(g7, 1e-6)
+    rec = enc_record(e)
+    dec = ref.decode(e, g7.shape)
+    rec["decoded_sha256"] = sha(dec)
+    rec.update(input_sha256=sha(g7), sin_factor=[hexf(v) for v in sx], cos_factor=[hexf(v) for v in cz], tolrel=1e-6,
+               linf_rel=float(np.abs(dec - g7).max() / np.abs(g7).max()))
+    G["G7_fortran_example_64"] = rec
+
     # ind_p2w_3d samples (row a3)
     pts = []
     for (n1, n2, n3) in ((64, 64, 64), (13, 9, 7), (5, 1, 33)):
