@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libwaverange_amd.so")
 ALIAS = os.path.join(HERE, "libwaverange.so")  # the reference's library name (drop-in link target)
 BIN = os.path.join(HERE, "bin")
 
-SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_api.cpp", "wr_dma.cpp", "wr_rangecoder.cpp", "wr_rangecoder_avx512.cpp", "wr_compat.cpp"]
+SOURCES = ["wr_kernels.hip", "wr_fused.hip", "wr_pipeline.cpp", "wr_codec.cpp", "wr_coder_hooks.cpp", "wr_dropin.cpp", "wr_dma.cpp", "wr_rangecoder.cpp", "wr_rangecoder_avx512.cpp", "wr_compat.cpp"]
 # per-file extra flags: the AVX-512 coder loop is only entered when the CPU has the instructions (vec_available)
 EXTRA = {"wr_rangecoder_avx512.cpp": ["-mavx512f", "-mavx512bw", "-mavx512dq", "-mavx512vl"]}
 CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", "cli/gen_io.cpp"],

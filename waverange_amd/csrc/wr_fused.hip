@@ -725,7 +725,7 @@ const char* fused_prepare()
 void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st,
                          double* mm_partial, double* mm_result)
 {
-    (void)fused_prepare();  // (callers check it before they choose this path: wr_api.cpp)
+    (void)fused_prepare();  // (callers check it before they choose this path: wr_pipeline.cpp, wr_codec.cpp)
     const size_t d_sy = (size_t)nx, d_sz = (size_t)nx * ny;
     const int nfused = fused_levels(nx, ny, nz, false);
     const bool mm = mm_partial != nullptr && nfused == 4;

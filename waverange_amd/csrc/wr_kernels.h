@@ -85,7 +85,7 @@ const char* fused_prepare();
 // mm_partial (fused_minmax_records() x 4 doubles, device) and mm_result (4 doubles, device): when given -- and all
 // four levels run fused -- the forward kernels also reduce min/max of the field read and of the coefficient array
 // written; mm_result = {field min, field max, coefficient min, coefficient max} (NaNs skipped, the sign of a zero
-// minimum is not defined here: see read_minmax in wr_api.cpp).
+// minimum is not defined here: see read_minmax in wr_pipeline.cpp).
 size_t fused_minmax_records(int nx, int ny, int nz);
 void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st,
                          double* mm_partial = nullptr, double* mm_result = nullptr);

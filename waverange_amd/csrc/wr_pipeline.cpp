@@ -1,0 +1,695 @@
+// wr_pipeline.cpp -- host side of libwaverange_amd: contexts, work-space slots, transfers, device-resident planes (see wr_internal.h for the other files).
+//
+// A call (wr_codec.cpp) moves through three device stages on one of a few work-space SLOTS per GPU:
+//   up      host -> device   field (encode)                                     SDMA engine (wr_dma.h)
+//   kernels min/max, transform, quantizer / dequantizer                         the context's stream, one call
+//                                                                               at a time (DevPool::cu_mu)
+//   down    device -> host   block histograms, residual (encode) or field       SDMA engine
+// The quantized planes are not part of the slot: they live in device buffers of their own (DevPlanes) and the host
+// range coder (one thread per plane, fewer with the planes of a field interleaved in one loop: wr_set_threads, or the
+// process-wide pool: wr_set_coder_pool) reads or writes them through a ring of two pinned 15 MB windows per plane
+// (PlaneStream, wrrc::PlaneWindow) while the slot already serves the next field.  Copies and kernels are ordered from
+// the host (HIP event of the producing kernel -> start the copy; signal of the copy -> launch the consumer); pageable
+// caller memory goes through hipMemcpyAsync on a copy stream instead.
+#include "wr_internal.h"
+
+namespace wri {
+
+thread_local std::string g_err;
+std::string& last_error() { return g_err; }
+std::atomic<int> g_verbose{-1};      // -1: not initialised from the environment yet
+std::atomic<int> g_threads{-1};      // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
+std::atomic<int> g_enc_threads{0};   // 0: same as g_threads (wr_set_encoder_threads)
+std::atomic<unsigned long> g_stat[4];  // see wr_stat()
+std::atomic<int> g_writeback{-1};    // drop-in encoding_wrap leaves the residual in fld_1d (-1: from WR_WRITEBACK_RESIDUAL, default 1)
+
+int coder_threads()
+{
+    int t = g_threads.load();
+    if (t < 0) {
+        const char* e = getenv("WR_THREADS");
+        const int k = e ? atoi(e) : 0;
+        t = k >= 1 ? k : WR_NLAYMAX;
+        g_threads.store(t);
+    }
+    return t;
+}
+int encoder_threads() { const int e = g_enc_threads.load(); return e > 0 ? e : coder_threads(); }
+
+int verbose()
+{
+    int v = g_verbose.load();
+    if (v < 0) {
+        const char* q = getenv("WR_QUIET");
+        v = (q && *q && *q != '0') ? 0 : 1;
+        g_verbose.store(v);
+    }
+    return v;
+}
+
+int writeback_residual()
+{
+    int v = g_writeback.load();
+    if (v < 0) {
+        const char* e = getenv("WR_WRITEBACK_RESIDUAL");
+        v = (e && *e) ? (atoi(e) ? 1 : 0) : 1;
+        g_writeback.store(v);
+    }
+    return v;
+}
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int ctx_bind(wr_ctx* c) { HIPCHK(hipSetDevice(c->device)); return WR_OK; }
+
+DevPool g_pools[kMaxDevices];
+std::mutex g_pools_mu;
+
+hipError_t slot_ensure(Slot* s, const SlotNeed& need)
+{
+    hipError_t e;
+    if ((e = grow(&s->field, &s->field_elems, need.field_elems)) != hipSuccess) return e;
+    if ((e = grow(&s->scratch, &s->scratch_elems, need.scratch_elems)) != hipSuccess) return e;
+    if ((e = grow(&s->lowbuf, &s->lowbuf_elems, need.lowbuf_elems)) != hipSuccess) return e;
+    if ((e = grow(&s->hist, &s->hist_elems, need.hist_elems)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
+{
+    if (c->enc_buf_bytes[l] >= bytes) return WR_OK;
+    free(c->enc_buf[l]);
+    c->enc_buf[l] = static_cast<uint8_t*>(malloc(bytes));
+    c->enc_buf_bytes[l] = c->enc_buf[l] ? bytes : 0;
+    return c->enc_buf[l] ? WR_OK : fail(WR_ERR_ARG, "out of host memory for the coded stream");
+}
+
+int ensure_host_hist(wr_ctx* c, size_t elems)
+{
+    if (c->h_hist_elems >= elems) return WR_OK;
+    if (c->h_hist) HIPCHK(hipHostFree(c->h_hist));
+    c->h_hist = nullptr; c->h_hist_elems = 0;
+    HIPCHK(hipHostMalloc(&c->h_hist, elems * sizeof(uint16_t), hipHostMallocDefault));
+    c->h_hist_elems = elems;
+    return WR_OK;
+}
+
+bool dma_enabled()
+{
+    static const bool on = !(getenv("WR_NO_DMA") && atoi(getenv("WR_NO_DMA")));
+    return on;
+}
+
+// Starts the pieces of one transfer: on a DMA engine where ROCr knows the host memory (pinned), through
+// hipMemcpyAsync on the device's copy stream of that direction otherwise.  Never blocks on the copies.
+int xfer_start(wr_ctx* c, wr_ctx::Xfer* x, const Piece* pc, int count, Dir dir)
+{
+    bool able[4] = {false, false, false, false};
+    int ndma = 0;
+    const bool use = x->sig && dma_enabled();
+    for (int k = 0; k < count; k++) { able[k] = use && wrdma::can_copy(pc[k].dst, pc[k].src); ndma += able[k]; }
+    std::lock_guard<std::mutex> lk(x->mu);
+    x->t_start = now();
+    x->ms = 0;
+    if (ndma) {
+        wrdma::signal_arm(x->sig, ndma);
+        x->dma_pending = true;
+        int started = 0;
+        for (int k = 0; k < count; k++) {
+            if (!able[k]) continue;
+            if (wrdma::copy_async(pc[k].dst, pc[k].src, pc[k].bytes, x->sig) != 0) {
+                wrdma::signal_cancel(x->sig, ndma - started);
+                return fail(WR_ERR_HIP, "DMA copy could not be queued");
+            }
+            started++;
+        }
+    }
+    if (ndma < count) {
+        DevPool* p = c->pool;
+        hipStream_t st = dir == kUp ? p->up : p->down;
+        StageLock lk(dir == kUp ? p->up_mu : p->down_mu);
+        for (int k = 0; k < count; k++)
+            if (!able[k])
+                HIPCHK(hipMemcpyAsync(pc[k].dst, pc[k].src, pc[k].bytes, dir == kUp ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(x->ev, st));
+        x->hip_pending = true;
+    }
+    return WR_OK;
+}
+
+// Waits for a transfer (no-op if none is pending).  May be called from any thread, any number of times.
+int xfer_wait(wr_ctx::Xfer* x)
+{
+    std::lock_guard<std::mutex> lk(x->mu);
+    int rc = WR_OK;
+    const bool timed_by_host = x->hip_pending;
+    if (x->hip_pending) {
+        if (hipEventSynchronize(x->ev) != hipSuccess) rc = fail(WR_ERR_HIP, "copy failed");
+        x->hip_pending = false;
+    }
+    if (x->dma_pending) {
+        if (wrdma::wait(x->sig) != 0) rc = fail(WR_ERR_HIP, "DMA copy failed");
+        x->dma_pending = false;
+        const double ms = wrdma::last_copy_ms(x->sig);
+        x->ms = (!timed_by_host && ms >= 0) ? ms : (now() - x->t_start) * 1e3;
+    } else if (timed_by_host) {
+        x->ms = (now() - x->t_start) * 1e3;
+    }
+    return rc;
+}
+
+// ---- device-resident planes and their host windows -------------------------------------------------------------------
+// a window: 256 coder blocks, 15.36 MB, ~0.3 ms on a DMA engine (WR_WINDOW_BLOCKS: 1..256 blocks, for tests that want
+// many windows on small fields)
+const size_t kChunkSyms = []() {
+    int blocks = 256;
+    if (const char* e = getenv("WR_WINDOW_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 256) blocks = v; }
+    return (size_t)blocks * wrrc::kBlock;
+}();
+const size_t kChunkBytes = 256 * (size_t)wrrc::kBlock + 64;  // ring buffers are always full-size
+
+void plane_release(wr_ctx* c, int l)
+{
+    PlaneStream& s = c->ps[l];
+    if (!s.dev) return;
+    DevPlanes::Buf b; b.p = s.dev; b.bytes = s.dev_bytes;
+    c->pool->planes.give(b);
+    s.dev = nullptr; s.dev_bytes = 0;
+}
+
+// Encoder side: the symbols [first, first + count) of the plane, fetched into the ring; the following chunk is
+// started into the buffer the coder has just left, so that it arrives while this one is being coded.
+uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
+{
+    PlaneStream& s = *static_cast<PlaneStream*>(user);
+    wr_ctx* const c = s.c;
+    (void)hipSetDevice(c->device);  // coder threads: the pageable-copy fallback of xfer_start needs the device bound
+    const size_t want = *count < kChunkSyms ? *count : kChunkSyms;
+    const int b = s.cur ^ 1;
+    if (!(s.ahead && s.ahead_first == first)) {
+        if (s.ahead) (void)xfer_wait(&s.x[b]);
+        const Piece pc = {s.buf[b], s.dev + first, want};
+        if (xfer_start(c, &s.x[b], &pc, 1, kDown) != WR_OK) s.err = 1;
+    }
+    if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;
+    s.copy_ms += s.x[b].ms;
+    s.cur = b;
+    s.ahead = false;
+    const size_t next = first + want;
+    if (next < s.n) {
+        const Piece pc = {s.buf[b ^ 1], s.dev + next, s.n - next < kChunkSyms ? s.n - next : kChunkSyms};
+        if (xfer_start(c, &s.x[b ^ 1], &pc, 1, kDown) == WR_OK) { s.ahead = true; s.ahead_first = next; }
+        else s.err = 1;
+    }
+    *count = want;
+    return s.buf[b];
+}
+
+// Decoder side: room for the symbols from `first` on; the window handed out before goes to the device meanwhile.
+// *count == 0 ends the stream: both uploads are waited for.
+uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
+{
+    PlaneStream& s = *static_cast<PlaneStream*>(user);
+    wr_ctx* const c = s.c;
+    (void)hipSetDevice(c->device);
+    if (s.win_count) {
+        const Piece pc = {s.dev + s.win_first, s.buf[s.cur], s.win_count};
+        if (xfer_start(c, &s.x[s.cur], &pc, 1, kUp) != WR_OK) s.err = 1;
+        s.win_count = 0;
+    }
+    if (*count == 0) {
+        for (int b = 0; b < 2; b++) { if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1; s.copy_ms += s.x[b].ms; s.x[b].ms = 0; }
+        return nullptr;
+    }
+    const int b = s.cur ^ 1;
+    if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;  // the upload of two windows ago
+    s.copy_ms += s.x[b].ms; s.x[b].ms = 0;
+    s.cur = b;
+    s.win_first = first;
+    s.win_count = *count < kChunkSyms ? *count : kChunkSyms;
+    *count = s.win_count;
+    return s.buf[b];
+}
+
+// plane l of n symbols for this call: a device buffer (kept if the context holds one that fits: a finish after a
+// begin), the ring, and the window callbacks of the direction
+int plane_prepare(wr_ctx* c, int l, size_t n, bool decode)
+{
+    PlaneStream& s = c->ps[l];
+    const size_t bytes = wr_plane_pitch(n);
+    if (!s.dev || s.dev_bytes < bytes) {
+        plane_release(c, l);
+        const DevPlanes::Buf b = c->pool->planes.take(bytes);
+        if (!b.p) return fail(WR_ERR_HIP, "out of device memory for a quantized plane (fewer calls in flight need less)");
+        s.dev = b.p; s.dev_bytes = b.bytes;
+    }
+    for (int b = 0; b < 2; b++) {
+        if (s.buf[b]) continue;
+        if (hipHostMalloc(reinterpret_cast<void**>(&s.buf[b]), kChunkBytes, hipHostMallocDefault) == hipSuccess) { s.buf_pinned[b] = true; continue; }
+        // no pinned memory left: a pageable window works (the copies are then staged by the runtime, xfer_start)
+        (void)hipGetLastError();
+        s.buf[b] = static_cast<uint8_t*>(aligned_alloc(4096, (kChunkBytes + 4095) / 4096 * 4096));
+        s.buf_pinned[b] = false;
+        if (!s.buf[b]) return fail(WR_ERR_ARG, "out of host memory for a plane window");
+    }
+    s.c = c; s.n = n;
+    s.cur = 1; s.win_first = s.win_count = 0; s.ahead = false; s.ahead_first = 0; s.err = 0; s.copy_ms = 0;
+    s.x[0].ms = s.x[1].ms = 0;
+    s.io.window = decode ? plane_window_decode : plane_window_encode;
+    s.io.user = &s;
+    return WR_OK;
+}
+
+// encode: the plane is complete on the device -- its first chunk sets off for the host before a coder asks for it
+void plane_prefetch(wr_ctx* c, int l)
+{
+    PlaneStream& s = c->ps[l];
+    if (!s.n) return;
+    const Piece pc = {s.buf[s.cur ^ 1], s.dev, s.n < kChunkSyms ? s.n : kChunkSyms};
+    if (xfer_start(c, &s.x[s.cur ^ 1], &pc, 1, kDown) == WR_OK) { s.ahead = true; s.ahead_first = 0; }
+    else s.err = 1;
+}
+
+// a whole plane on the host, for the diagnostics of the verbose mode (wrappers.cpp:401-409, 503-510)
+std::string plane_log(wr_ctx* c, int l, size_t n, const wr_enc_info* info, bool encode, size_t len)
+{
+    std::vector<uint8_t> q(n);
+    if (hipMemcpy(q.data(), c->ps[l].dev, n, hipMemcpyDeviceToHost) != hipSuccess) return std::string();
+    unsigned lo = q[0], hi = q[0];
+    for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    char b[256];
+    if (encode)
+        snprintf(b, sizeof b, "imin=%u imax=%u med=%g\nlen_out_q=%lu ntot=%lu\n", lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l],
+                 (unsigned long)len, (unsigned long)n);
+    else
+        snprintf(b, sizeof b, "ilay=%d\nimin=%u imax=%u med=%g\n", l, lo, hi, q[n / 2] * info->deps_vec[l] + info->minval_vec[l]);
+    return b;
+}
+
+bool use_fused(int nx, int ny, int nz, int lvl)
+{
+    return wrk::fused_ok(nx, ny, nz, lvl) && !getenv("WR_NO_FUSED");
+}
+
+// work space a transform of this shape needs next to the field itself
+void transform_need(int nx, int ny, int nz, int lvl, SlotNeed* need)
+{
+    need->scratch_elems = (size_t)nx * ny * nz;
+    if (use_fused(nx, ny, nz, lvl)) need->lowbuf_elems = wrk::fused_lowbuf_elems(nx, ny, nz);
+}
+
+// Forward (lvl > 0) or inverse (lvl < 0) transform of d_fld.  The fused path is out of place: the result
+// lands in the slot's scratch buffer and *out points there; the general path works in place.
+int run_transform(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int lvl, double** out)
+{
+    *out = d_fld;
+    if (use_fused(nx, ny, nz, lvl)) {
+        if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
+        if (lvl > 0) wrk::transform_fwd_fused(d_fld, s->scratch, s->lowbuf, nx, ny, nz, c->stream);
+        else wrk::transform_inv_fused(d_fld, s->scratch, s->lowbuf, nx, ny, nz, c->stream);
+        *out = s->scratch;
+    } else {
+        wrk::transform(d_fld, s->scratch, nx, ny, nz, lvl, c->stream);
+    }
+    return WR_OK;
+}
+
+// decoder back end: acc = sum of planes, then the inverse transform, result in d_fld.
+// Fused path: accumulate into the scratch buffer and transform out of place into d_fld.
+// Records ev_a / ev_b / ev_c around the two stages (for the timings).
+int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int wlev, const wrk::DequantParams& p)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    const bool fused = wlev == 4 && use_fused(nx, ny, nz, -4);
+    if (fused) if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
+    HIPCHK(hipEventRecord(c->ev_a, c->stream));
+    wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
+    HIPCHK(hipEventRecord(c->ev_b, c->stream));
+    if (fused) wrk::transform_inv_fused(s->scratch, d_fld, s->lowbuf, nx, ny, nz, c->stream);
+    else wrk::transform(d_fld, s->scratch, nx, ny, nz, -wlev, c->stream);
+    HIPCHK(hipEventRecord(c->ev_c, c->stream));
+    return WR_OK;
+}
+
+// min/max of a device array with the reference's scan semantics (wrappers.cpp:244-250):
+// values from the reduction; if the minimum is a zero, its sign is that of the LAST zero in
+// memory order (glibc fmin keeps the later of equal operands -- oracle/wr_oracle.c:wro_minmax).
+// `pending` = a fused kernel has already been enqueued that stores the reduction into h_result[0..1].
+// Waits on an event recorded right behind the read-back, so kernels enqueued afterwards do not
+// delay the answer.
+int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn, double* mx)
+{
+    // the final reduction kernel stores min and max straight into pinned host memory: no copy command
+    if (!pending) wrk::minmax(d_x, n, c->d_partial, c->h_result_dev, c->stream);
+    HIPCHK(hipEventRecord(c->ev_mm, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_mm));
+    double lo = c->h_result[0], hi = c->h_result[1];
+    if (lo == 0.0) {
+        wrk::last_zero_index(d_x, n, c->d_idx, c->stream);
+        unsigned long long* hidx = reinterpret_cast<unsigned long long*>(c->h_result + 3);
+        HIPCHK(hipMemcpyAsync(hidx, c->d_idx, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (*hidx) {
+            HIPCHK(hipMemcpyAsync(c->h_result + 2, d_x + (*hidx - 1), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            lo = c->h_result[2];
+        }
+    }
+    *mn = lo; *mx = hi;
+    return WR_OK;
+}
+
+int check_dims(int nx, int ny, int nz, const void* dev_ptr)
+{
+    if (nx < 1 || ny < 1 || nz < 1) return fail(WR_ERR_ARG, "non-positive dimension");
+    if (((uintptr_t)dev_ptr) & 15) return fail(WR_ERR_ARG, "device field pointer must be 16-byte aligned");
+    return WR_OK;
+}
+
+}  // namespace wri
+
+using namespace wri;
+
+// =====================================================================================
+// Part 2: device-resident API -- settings, contexts, memory helpers, stage-level entry points
+// =====================================================================================
+extern "C" {
+
+const char* wr_last_error(void) { return last_error().c_str(); }
+
+int wr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void wr_set_verbosity(int level) { g_verbose.store(level ? 1 : 0); }
+void wr_set_threads(int nthreads) { g_threads.store(nthreads < 1 ? 1 : nthreads); g_enc_threads.store(0); }
+void wr_set_encoder_threads(int nthreads) { g_enc_threads.store(nthreads < 0 ? 0 : nthreads); }
+void wr_set_writeback_residual(int on) { g_writeback.store(on ? 1 : 0); }
+void wr_pool_loop_stats(double* seconds4, double* blocks4) { wrrc::pool_loop_stats(seconds4, blocks4); }
+
+unsigned long wr_stat(int what)
+{
+    if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
+    return (what >= 0 && what < 4) ? g_stat[what].load() : 0;
+}
+void wr_set_coder_pool(int nthreads, int decoder_streams)
+{
+    wrrc::pool_configure(nthreads < 0 ? 0 : nthreads, decoder_streams);
+}
+
+int wr_set_device_slots(int device, int nslots)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(WR_ERR_ARG, "device index out of range");
+    if (nslots < 1) nslots = 1;
+    if (nslots > kMaxSlots) nslots = kMaxSlots;
+    DevPool* p = &g_pools[device];
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (int i = nslots; i < kMaxSlots; i++)
+        if (p->slots[i].busy || p->slots[i].allocated()) return fail(WR_ERR_ARG, "slots beyond the new count are in use");
+    p->max_slots = nslots;
+    for (Slot& s : p->slots) s.disabled = false;
+    return WR_OK;
+}
+
+static int ctx_init(wr_ctx* c, int device, void* hip_stream)
+{
+    HIPCHK(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        DevPool* p = c->pool;
+        if (!p->up) {
+            if (const char* e = getenv("WR_SLOTS")) { const int k = atoi(e); if (k >= 1) p->max_slots = k > kMaxSlots ? kMaxSlots : k; }
+            HIPCHK(hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
+        }
+        if (!p->down) HIPCHK(hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
+    }
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIPCHK(hipMalloc(&c->d_partial, 2 * wrk::minmax_partials() * sizeof(double)));
+    HIPCHK(hipMalloc(&c->d_idx, sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc(&c->h_result, 8 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_result_dev), c->h_result, 0));
+    for (int i = 0; i < WR_NLAYMAX; i++) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_plane[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreate(&c->ev_a)); HIPCHK(hipEventCreate(&c->ev_b));
+    HIPCHK(hipEventCreate(&c->ev_c)); HIPCHK(hipEventCreate(&c->ev_d));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
+    std::vector<wr_ctx::Xfer*> xs = {&c->x_field};
+    for (int l = 0; l < WR_NLAYMAX; l++) { xs.push_back(&c->x_plane[l]); xs.push_back(&c->ps[l].x[0]); xs.push_back(&c->ps[l].x[1]); }
+    for (wr_ctx::Xfer* x : xs) {
+        x->sig = wrdma::signal_create();  // 0 if ROCr is not usable: every copy then goes through hipMemcpyAsync
+        HIPCHK(hipEventCreateWithFlags(&x->ev, hipEventDisableTiming));
+    }
+    return WR_OK;
+}
+
+int wr_ctx_create(wr_ctx** out, int device, void* hip_stream)
+{
+    if (!out) return fail(WR_ERR_ARG, "null ctx pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(WR_ERR_HIP, std::string("no usable HIP device (") + hipGetErrorString(e) +
+                                    "): libwaverange_amd has no CPU fallback");
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(WR_ERR_ARG, "device index out of range");
+    wr_ctx* c = new (std::nothrow) wr_ctx;
+    if (!c) return fail(WR_ERR_ARG, "out of host memory");
+    c->device = device;
+    c->pool = &g_pools[device];
+    { std::lock_guard<std::mutex> lk(g_pools_mu); c->pool->users++; }
+    const int rc = ctx_init(c, device, hip_stream);
+    if (rc != WR_OK) {
+        const std::string msg = g_err;
+        wr_ctx_destroy(c);  // releases whatever was created, and the pool reference
+        g_err = msg;
+        return rc;
+    }
+    *out = c;
+    return WR_OK;
+}
+
+void wr_ctx_destroy(wr_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_cutoff);
+    (void)hipFree(c->d_partial); (void)hipFree(c->d_idx); (void)hipFree(c->d_mm);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_hist) (void)hipHostFree(c->h_hist);
+    for (int l = 0; l < WR_NLAYMAX; l++) {
+        (void)xfer_wait(&c->ps[l].x[0]); (void)xfer_wait(&c->ps[l].x[1]);
+        plane_release(c, l);
+        for (int b = 0; b < 2; b++)
+            if (c->ps[l].buf[b]) { if (c->ps[l].buf_pinned[b]) (void)hipHostFree(c->ps[l].buf[b]); else free(c->ps[l].buf[b]); }
+        free(c->enc_buf[l]);
+    }
+    for (int i = 0; i < WR_NLAYMAX; i++) {
+        if (c->ev_plane[i]) (void)hipEventDestroy(c->ev_plane[i]);
+    }
+    for (hipEvent_t ev : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_mm})
+        if (ev) (void)hipEventDestroy(ev);
+    std::vector<wr_ctx::Xfer*> xs = {&c->x_field};
+    for (int l = 0; l < WR_NLAYMAX; l++) { xs.push_back(&c->x_plane[l]); xs.push_back(&c->ps[l].x[0]); xs.push_back(&c->ps[l].x[1]); }
+    for (wr_ctx::Xfer* x : xs) {
+        wrdma::signal_destroy(x->sig);
+        if (x->ev) (void)hipEventDestroy(x->ev);
+    }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    {   // the last context on a device releases the shared work space
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        DevPool* p = c->pool;
+        if (--p->users == 0) {
+            std::lock_guard<std::mutex> sl(p->mu);
+            if (p->up) { (void)hipStreamSynchronize(p->up); (void)hipStreamDestroy(p->up); p->up = nullptr; }
+            if (p->down) { (void)hipStreamSynchronize(p->down); (void)hipStreamDestroy(p->down); p->down = nullptr; }
+            for (Slot& s : p->slots) s.release_buffers();
+            p->planes.drop_idle();
+        }
+    }
+    delete c;
+}
+
+int wr_ctx_sync(wr_ctx* c)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return WR_OK;
+}
+
+void wr_ctx_set_keep_residual(wr_ctx* c, int keep) { c->keep_residual = keep != 0; }
+
+int wr_dev_alloc(wr_ctx* c, void** ptr, size_t bytes)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipMalloc(ptr, bytes ? bytes : 16));
+    return WR_OK;
+}
+
+int wr_dev_free(wr_ctx* c, void* ptr)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipFree(ptr));
+    return WR_OK;
+}
+
+int wr_host_alloc(void** ptr, size_t bytes)
+{
+    HIPCHK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return WR_OK;
+}
+
+int wr_host_free(void* ptr)
+{
+    HIPCHK(hipHostFree(ptr));
+    return WR_OK;
+}
+
+int wr_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(WR_ERR_ARG, "wr_host_register: empty range");
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return WR_OK;
+}
+
+int wr_host_unregister(void* ptr)
+{
+    HIPCHK(hipHostUnregister(ptr));
+    return WR_OK;
+}
+
+int wr_dev_upload(wr_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));  // ordered behind what the context has queued, like a stream copy
+    if (bytes >= (1u << 20) && c->x_field.sig && wrdma::can_copy(dst, src)) {  // pinned host memory: SDMA engine
+        std::lock_guard<std::mutex> lk(c->mu);
+        wrdma::signal_arm(c->x_field.sig, 1);
+        if (wrdma::copy_async(dst, src, bytes, c->x_field.sig) != 0) { wrdma::signal_cancel(c->x_field.sig, 1); return fail(WR_ERR_HIP, "DMA copy could not be queued"); }
+        return wrdma::wait(c->x_field.sig) == 0 ? WR_OK : fail(WR_ERR_HIP, "DMA copy failed");
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return WR_OK;
+}
+
+int wr_dev_download(wr_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bytes >= (1u << 20) && c->x_field.sig && wrdma::can_copy(dst, src)) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        wrdma::signal_arm(c->x_field.sig, 1);
+        if (wrdma::copy_async(dst, src, bytes, c->x_field.sig) != 0) { wrdma::signal_cancel(c->x_field.sig, 1); return fail(WR_ERR_HIP, "DMA copy could not be queued"); }
+        return wrdma::wait(c->x_field.sig) == 0 ? WR_OK : fail(WR_ERR_HIP, "DMA copy failed");
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return WR_OK;
+}
+
+int wr_dev_copy_kernel(wr_ctx* c, void* dst, const void* src, size_t bytes, int workgroups)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) || workgroups < 1) return fail(WR_ERR_ARG, "copy kernel: 16-byte granularity");
+    wrk::copy_kernel(dst, src, bytes, workgroups, c->stream);
+    HIPCHK(hipGetLastError());
+    return WR_OK;
+}
+
+int wr_dev_copy(wr_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    StageLock cu(c->pool->cu_mu);  // a kernel stage like any other: keeps it off other contexts' transforms
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return WR_OK;
+}
+
+int wr_dev_linf(wr_ctx* c, const double* d_a, const double* d_b, size_t n, double* max_abs_diff, double* max_abs_a)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (!n) return fail(WR_ERR_ARG, "empty array");
+    wrk::linf_diff(d_a, d_b, n, c->d_partial, c->h_result_dev, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *max_abs_diff = c->h_result[0];
+    *max_abs_a = c->h_result[1];
+    return WR_OK;
+}
+
+int wr_dev_transform(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int lvl)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (int rc = check_dims(nx, ny, nz, d_fld)) return rc;
+    SlotNeed need;
+    transform_need(nx, ny, nz, lvl, &need);
+    SlotLease slot;
+    if (int rc = slot.acquire(c, need)) return rc;
+    StageLock cu(c->pool->cu_mu);
+    double* res = nullptr;
+    if (int rc = run_transform(c, slot.get(), d_fld, nx, ny, nz, lvl, &res)) return rc;
+    if (res != d_fld)
+        HIPCHK(hipMemcpyAsync(d_fld, res, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));  // the work space goes back with the lease
+    return WR_OK;
+}
+
+int wr_dev_minmax(wr_ctx* c, const double* d_x, size_t n, double* mn, double* mx)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (!n) return fail(WR_ERR_ARG, "empty array");
+    return read_minmax(c, d_x, n, false, mn, mx);
+}
+
+int wr_dev_quantize_plane(wr_ctx* c, double* d_x, size_t n, double deps, double minval, unsigned char* d_q,
+                          double* next_min, double* next_max)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 1)) return fail(WR_ERR_ARG, "misaligned device pointer");
+    const double aopt = 1.0 / deps;
+    const double bopt = -minval * aopt + 0.5;
+    wrk::quantize_plane(d_x, n, aopt, bopt, deps, minval, d_q, true, c->d_partial, c->h_result_dev, c->stream);
+    HIPCHK(hipGetLastError());
+    return read_minmax(c, d_x, n, true, next_min, next_max);
+}
+
+int wr_dev_dequant_accum(wr_ctx* c, double* d_acc, size_t n, int nlay, const unsigned char* const* d_planes,
+                         const double* deps, const double* minval)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (nlay < 0 || nlay > WR_NLAYMAX) return fail(WR_ERR_ARG, "nlay out of range");
+    wrk::DequantParams p;
+    memset(&p, 0, sizeof p);
+    p.nlay = nlay;
+    for (int l = 0; l < nlay; l++) { p.q[l] = d_planes[l]; p.deps[l] = deps[l]; p.minval[l] = minval[l]; }
+    wrk::dequant_accum(d_acc, n, p, c->stream);
+    HIPCHK(hipGetLastError());
+    return WR_OK;
+}
+
+int wr_dev_synth_field(wr_ctx* c, double* d_out, int nx, int ny, int nz, unsigned long long seed)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    wrk::synth_field(d_out, nx, ny, nz, seed, 0, nz, c->stream);
+    HIPCHK(hipGetLastError());
+    return WR_OK;
+}
+
+size_t wr_plane_pitch(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // extern "C"

@@ -22,7 +22,7 @@ constexpr int kMaxDecStreams = 4;   // ... by a pool worker's decoder loop (5 an
 size_t encode_bound(size_t n);
 
 // Windowed access to the symbol side of a plane that is not in host memory as a whole (it lives in device memory and
-// passes through a small pinned ring, wr_api.cpp).  `count` comes in as what is left of the plane from `first` on and
+// passes through a small pinned ring, wr_pipeline.cpp).  `count` comes in as what is left of the plane from `first` on and
 // goes out as the length of the window handed back: a multiple of kBlock unless the plane ends in it.
 //   encoder: the symbols [first, first + count); the pointer stays valid until the next call.
 //   decoder: room for the symbols [first, first + count); the window handed out before is complete by then.  A call
