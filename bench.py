@@ -160,7 +160,7 @@ def take_cpu_share(local_rank, gpus_on_node):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1):
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=1.5):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -196,7 +196,7 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # with the coder pool the lanes are not threads: a field in flight spends part of its time in copies and kernels and
     # waiting for its slowest plane, so 1.5 fields in flight per CPU keep the pool's workers busy (16 lanes on 16 CPUs:
     # 12.2 CPUs busy on average)
-    by_cpu = int(1.5 * cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
+    by_cpu = int(fields_per_cpu * cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
     # host memory per field in flight: the coded streams only (two hand-over buffers that have each held a 1e-7 field's
     # 2 GB at some point, and the coder's output while it is being produced: ~0.6 field sizes at the bench's tolerances,
     # 0.75 budgeted) and the pinned rings (0.25 GiB) -- the quantized planes stay in HBM; the input
@@ -206,7 +206,8 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     per_lane = 0.75 * field_bytes
     fixed = (1 + out_pool) * field_bytes if host_mode else 0
     by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
-    by_hbm = int((0.92 * hbm_free - 3 * 2.2 * field_bytes) // ((1.0 if host_mode else 3.0) * field_bytes * ntols))
+    # (planes_per_field: 1 byte per element and plane, encoder and decoder context of a lane each hold a field's planes)
+    by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / mem_share / 2 ** 30, 1) if mem else None,
                   "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
@@ -330,6 +331,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jobs", type=int, default=12, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
+    ap.add_argument("--fields-per-cpu", type=float, default=1.5, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
@@ -398,7 +400,8 @@ def main():
     # streams) and the free HBM (the quantized planes of the fields in flight live there).  --jobs is the upper bound.
     share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
     jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
-                            pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev)
+                            pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev, nslots=args.slots or 3,
+                            planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
     limits["cpu_affinity_share"] = share
     pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
     if pool_workers:

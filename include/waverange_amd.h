@@ -172,9 +172,11 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
 #define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */
 unsigned long wr_stat(int what);
-/* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder, 16-lane encoder}: seconds the workers have
- * spent in block steps of that loop and stream-blocks (60000 symbols) advanced: symbols per worker-second in the pipeline */
-void wr_pool_loop_stats(double *seconds4, double *blocks4);
+/* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder,
+ * 16-lane decoder for planes of any statistics} -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block
+ * steps of that loop and stream-blocks (60000 symbols) advanced: symbols per worker-second in the pipeline */
+#define WR_POOL_LOOP_KINDS 5
+void wr_pool_loop_stats(double *seconds, double *blocks);
 
 /* One context per concurrent caller: (device, kernel stream, coded-stream buffers, and per plane a ring
  * of two 15 MB pinned chunks), grown on demand and kept.  The device work space (wr_set_device_slots)
@@ -305,11 +307,15 @@ int wr_range_encode_vec(int count, const unsigned char *const *sym, const size_t
                         unsigned char *const *out, size_t *lens);
 int wr_range_decode_vec(int count, const unsigned char *const *in, const size_t *len,
                         unsigned char *const *sym, const size_t *n, size_t *produced);
+/* the decoder's 16-lane loop for planes of ANY statistics (low / help by vector division, table look-ups per lane: what
+ * noise planes need; the pool routes the decoder planes above 2 bits per symbol there) */
+int wr_range_decode_vec_any(int count, const unsigned char *const *in, const size_t *len,
+                            unsigned char *const *sym, const size_t *n, size_t *produced);
 
 /* Test hooks for the windowed symbol path: planes that live in device memory reach the host coder through a small
  * pinned ring, window by window (wr_encode_host / wr_decode_*); here the windows are `chunk` symbols (a multiple of
  * 60000) of plain host buffers.  mode 0: interleaved loops on the calling thread, 1: the coder pool, 2: the 16-lane
- * loops.  Same bytes / symbols as the whole-plane functions above. */
+ * loops, 3: (decode) the 16-lane loop for planes of any statistics.  Same bytes / symbols as the whole-plane functions above. */
 int wr_range_encode_windowed(int mode, int count, const unsigned char *const *sym, size_t n, size_t chunk,
                              unsigned char *const *out, size_t *lens);
 int wr_range_decode_windowed(int mode, int count, const unsigned char *const *in, const size_t *len,

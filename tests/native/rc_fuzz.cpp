@@ -95,6 +95,22 @@ int main() {
                 for (int k = 0; k < count; k++)
                     if (k != victim && (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k]))) { printf("vector: healthy stream disturbed\n"); return 1; }
             }
+            // the decoder's loop for planes of any statistics: the same planes, exact-size streams, damaged ones among healthy ones
+            for (int k = 0; k < count; k++) memset(back[k].data(), 0xEE, n[k]);
+            wrrc::decode_planes_vec(count, ip.data(), len.data(), bp.data(), n.data(), got.data(), nullptr, true);
+            for (int k = 0; k < count; k++)
+                if (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k])) { printf("any-statistics vector decode failed k=%d\n", k); return 1; }
+            for (int trial = 0; trial < 6; trial++) {
+                const int victim = (int)(rnd() % count);
+                std::vector<uint8_t> bad(enc[victim]);
+                if (trial < 2) bad.resize(bad.size() * (trial + 1) / 3);
+                else for (int j = 0; j < 16; j++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
+                std::vector<const uint8_t*> ip2(ip); std::vector<size_t> l2(len);
+                ip2[victim] = bad.data(); l2[victim] = bad.size();
+                wrrc::decode_planes_vec(count, ip2.data(), l2.data(), bp.data(), n.data(), got.data(), nullptr, true);
+                for (int k = 0; k < count; k++)
+                    if (k != victim && (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k]))) { printf("any-statistics vector: healthy stream disturbed\n"); return 1; }
+            }
             // the encoder's vector loop: exact-size output is not possible (the length is the result), so the
             // buffers have the documented bound and the bytes are compared
             std::vector<std::vector<uint8_t>> venc(count);
@@ -163,7 +179,7 @@ int main() {
                 ioe[k] = wrrc::PlaneWindow{Win::fn, &we[k]}; iod[k] = wrrc::PlaneWindow{Win::fn, &wd[k]};
                 pe[k] = &ioe[k]; pd[k] = &iod[k]; ip[k] = enc[k].data(); op[k] = wenc[k].data();
             }
-            for (int mode = 0; mode < 2; mode++) {
+            for (int mode = 0; mode < 3; mode++) {  // 2: the decoder's loop for planes of any statistics
                 if (mode == 0) wrrc::encode_planes(count, none.data(), n, op.data(), nullptr, wlen.data(), pe.data());
                 else if (!wrrc::encode_planes_vec(count, none.data(), ns.data(), op.data(), wlen.data(), pe.data())) continue;
                 for (int k = 0; k < count; k++) {
@@ -172,7 +188,7 @@ int main() {
                 }
                 for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
                 if (mode == 0) wrrc::decode_planes(count, ip.data(), len.data(), noned.data(), n, got.data(), pd.data());
-                else wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data());
+                else wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data(), mode == 2);
                 for (int k = 0; k < count; k++)
                     if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("windowed decode failed n=%zu mode=%d k=%d\n", n, mode, k); return 1; }
                 // a truncated and a corrupted stream among healthy ones
@@ -183,7 +199,7 @@ int main() {
                     ip2[1] = bad.data(); l2[1] = bad.size();
                     for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
                     if (mode == 0) wrrc::decode_planes(count, ip2.data(), l2.data(), noned.data(), n, got.data(), pd.data());
-                    else wrrc::decode_planes_vec(count, ip2.data(), l2.data(), noned.data(), ns.data(), got.data(), pd.data());
+                    else wrrc::decode_planes_vec(count, ip2.data(), l2.data(), noned.data(), ns.data(), got.data(), pd.data(), mode == 2);
                     for (int k = 0; k < count; k++)
                         if (k != 1 && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("windowed: healthy stream disturbed\n"); return 1; }
                 }
@@ -257,10 +273,10 @@ int main() {
                 wd[k] = Win{back[k].data(), n, (size_t)60000 * (1 + (k + trial) % 3), nullptr, 0, 0};
                 iod[k] = wrrc::PlaneWindow{Win::fn, &wd[k]}; pd[k] = &iod[k];
             }
-            for (int mode = 0; mode < 2; mode++) {
+            for (int mode = 0; mode < 3; mode++) {
                 for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
                 if (mode == 0) wrrc::decode_planes(count, ip.data(), len.data(), noned.data(), n, got.data(), pd.data());
-                else if (!wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data())) continue;
+                else if (!wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data(), mode == 2)) continue;
                 for (int k = 0; k < count; k++)
                     if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("ragged blocks: windowed decode differs trial=%d mode=%d k=%d got=%zu\n", trial, mode, k, got[k]); return 1; }
             }

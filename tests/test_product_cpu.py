@@ -274,6 +274,15 @@ def test_avx512_decoder_loop_same_symbols(oracle):
         pytest.skip("no AVX-512 on this CPU")
     for i, (d, g, p) in enumerate(zip(dec, got, planes)):
         assert g == p.size and np.array_equal(d, p), (i, p.size)
+    # the same planes, and noise planes of several shapes, through the 16-lane loop for planes of ANY statistics (low / help by
+    # vector division, table look-ups per lane): more planes than lanes, streams joining and leaving at block boundaries
+    more = [rs.randint(0, 256, 300000 + 777 * k).astype(np.uint8) for k in range(6)]
+    more += [np.clip(np.rint(rs.normal(128, 30, 360000)), 0, 255).astype(np.uint8), rs.randint(0, 2, 240000).astype(np.uint8) * 255,
+             np.where(rs.random_sample(300000) < 0.5, 255, rs.randint(0, 256, 300000)).astype(np.uint8)]  # the largest symbol is frequent
+    aplanes, aenc = planes + more, enc + [oracle.range_encode(p) for p in more]
+    dec, got = api.range_decode_vec(aenc, [p.size for p in aplanes], any_statistics=True)
+    for i, (d, g, p) in enumerate(zip(dec, got, aplanes)):
+        assert g == p.size and np.array_equal(d, p), ("any-statistics loop", i, p.size)
     # the encoder's vector loop (candidate compares; rare other symbols through the lane's table; noise planes and
     # partial blocks through the scalar code of their stream)
     planes.append(np.where(rs.random_sample(300000) < 0.995, 255, rs.randint(0, 256, 300000)).astype(np.uint8))
@@ -313,12 +322,12 @@ def test_windowed_symbol_access_same_bytes_as_oracle(oracle, n):
     api.set_coder_pool(3, 4)
     try:
         for chunk in (60000, 120000):
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):  # 3: the decoder's 16-lane loop for planes of any statistics (encoder as mode 2)
                 try:
-                    enc = api.range_encode_windowed(planes, chunk, mode)
+                    enc = api.range_encode_windowed(planes, chunk, min(mode, 2))
                     dec, got = api.range_decode_windowed(want, n, chunk, mode)
                 except api.WaveRangeError:
-                    assert mode == 2  # no AVX-512 on this CPU
+                    assert mode >= 2  # no AVX-512 on this CPU
                     continue
                 for i, (a, b) in enumerate(zip(enc, want)):
                     assert np.array_equal(a, b), ("encode", chunk, mode, i)

@@ -137,6 +137,7 @@ def lib():
     L.wr_range_encode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_range_decode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_decode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.wr_range_decode_vec_any.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_encode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_range_encode_windowed.argtypes = [C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
     L.wr_range_decode_windowed.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]
@@ -189,9 +190,9 @@ def stat(what):
 
 def pool_loop_stats():
     """{loop kind: (worker seconds in block steps, stream-blocks advanced)} since the process started."""
-    sec, blk = (C.c_double * 4)(), (C.c_double * 4)()
+    sec, blk = (C.c_double * 5)(), (C.c_double * 5)()
     lib().wr_pool_loop_stats(sec, blk)
-    return {k: (sec[i], blk[i]) for i, k in enumerate(("scalar_encoder", "scalar_decoder", "vector_decoder", "vector_encoder"))}
+    return {k: (sec[i], blk[i]) for i, k in enumerate(("scalar_encoder", "scalar_decoder", "vector_decoder", "vector_encoder", "vector_decoder_any"))}
 
 
 def set_writeback_residual(on):
@@ -330,13 +331,15 @@ def range_encode_vec(planes):
     return [o[:lens[i]].copy() for i, o in enumerate(outs)]
 
 
-def range_decode_vec(streams, ns):
-    """Planes through the 16-lane AVX-512 decoder loop on this thread (raises on CPUs without AVX-512)."""
+def range_decode_vec(streams, ns, any_statistics=False):
+    """Planes through the 16-lane AVX-512 decoder loop on this thread (raises on CPUs without AVX-512); any_statistics: the
+    loop for planes without dominant symbols (noise planes) instead of the candidate-compare loop."""
     ss = [np.ascontiguousarray(s, dtype=np.uint8).ravel() for s in streams]
     k = len(ss)
     outs = [np.zeros(max(n, 1), dtype=np.uint8) for n in ns]
     got = (C.c_size_t * k)()
-    _check(lib().wr_range_decode_vec(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
+    fn = lib().wr_range_decode_vec_any if any_statistics else lib().wr_range_decode_vec
+    _check(fn(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
                                      (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*ns), got))
     return [o[:n] for o, n in zip(outs, ns)], [got[i] for i in range(k)]
 

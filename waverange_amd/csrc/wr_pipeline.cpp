@@ -397,7 +397,7 @@ void wr_set_verbosity(int level) { g_verbose.store(level ? 1 : 0); }
 void wr_set_threads(int nthreads) { g_threads.store(nthreads < 1 ? 1 : nthreads); g_enc_threads.store(0); }
 void wr_set_encoder_threads(int nthreads) { g_enc_threads.store(nthreads < 0 ? 0 : nthreads); }
 void wr_set_writeback_residual(int on) { g_writeback.store(on ? 1 : 0); }
-void wr_pool_loop_stats(double* seconds4, double* blocks4) { wrrc::pool_loop_stats(seconds4, blocks4); }
+void wr_pool_loop_stats(double* seconds, double* blocks) { wrrc::pool_loop_stats(seconds, blocks); }
 
 unsigned long wr_stat(int what)
 {

@@ -968,7 +968,19 @@ uint32_t vec_other_symbol(const void* model, uint32_t* low, uint32_t* range, uin
 class VecDecGroup {
 public:
     static constexpr int kCap = kVecLanes;
-    VecDecGroup() : models_((size_t)kCap) { for (int k = 0; k < kCap; k++) ms_[k] = &models_[k]; }
+    // any: the loop for planes of any statistics (vec_decode_block_any: division + table look-ups per lane) instead of
+    // the candidate-compare loop for dominant-symbol planes
+    explicit VecDecGroup(bool any = false) : any_(any), models_((size_t)kCap)
+    {
+        for (int k = 0; k < kCap; k++) ms_[k] = &models_[k];
+        if (any_) {
+            arena_.reset(static_cast<uint8_t*>(aligned_alloc(64, (size_t)kCap * kAnyStride)));
+            packed_.reset(static_cast<uint32_t*>(aligned_alloc(64, (size_t)kCap * 256 * sizeof(uint32_t))));
+            if (!arena_ || !packed_) throw std::bad_alloc();
+            memset(arena_.get(), 0, (size_t)kCap * kAnyStride);
+            memset(packed_.get(), 0, (size_t)kCap * 256 * sizeof(uint32_t));
+        }
+    }
     int count() const { return count_; }
     bool full() const { return count_ == kCap; }
     void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag, const PlaneWindow* io = nullptr)
@@ -999,7 +1011,10 @@ public:
                     if (c) top_sym = (uint32_t)b;
                 }
                 if (bs > kBlock) { failed_[k] = true; ended = true; }
-                else { m.top = top_sym; m.bs = bs; finish_model_stats(m); }
+                else {
+                    m.top = top_sym; m.bs = bs;
+                    if (any_) m.tables_ready = false; else finish_model_stats(m);
+                }
             }
             if (ended) { retire(k, on_end); continue; }
             const size_t at = produced_[k] < n_[k] ? produced_[k] : n_[k];
@@ -1010,10 +1025,11 @@ public:
                 d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
             }
             const bool fast = m.bs == kBlock && cur_[k].room(at) >= kBlock && d.pos + kMargin <= d.len;
-            vec[k] = fast && m.cand_ok;
+            vec[k] = fast && (any_ || m.cand_ok);
             k++;
         }
         if (!count_) return;
+        if (any_) { step_any(vec); finish_slow(vec, on_end); return; }
         VecBlock vb;
         vb.active = 0;
         for (int k = 0; k < count_; k++) {
@@ -1039,6 +1055,15 @@ public:
                 produced_[k] += kBlock;
             }
         }
+        finish_slow(vec, on_end);
+    }
+
+private:
+    // the lanes the vector loop did not take in this step (partial block, window or stream about to end; no dominant
+    // symbols in the candidate mode): scalar, checked
+    template <class OnEnd>
+    void finish_slow(bool* vec, OnEnd on_end)
+    {
         for (int k = 0; k < count_;) {
             if (vec[k]) { k++; continue; }
             BlockModel& m = *ms_[k];
@@ -1055,8 +1080,40 @@ public:
             k++;
         }
     }
+    // the full blocks of this step through vec_decode_block_any: per lane the symbol-of-cumulative-frequency table (60 KB,
+    // rebuilt per block like the scalar loop's) and the packed {lt, sy} entries
+    void step_any(const bool* vec)
+    {
+        VecAnyBlock vb;
+        vb.active = 0;
+        vb.lookup = arena_.get();
+        vb.packed = packed_.get();
+        for (int k = 0; k < count_; k++) {
+            if (!vec[k]) continue;
+            const Dec& d = *ds_[k];
+            const BlockModel& m = *ms_[k];
+            vb.active |= 1u << k;
+            vb.low[k] = d.low; vb.range[k] = d.range; vb.ptr[k] = d.in + d.pos; vb.dst[k] = dst_[k];
+            uint8_t* const lk = arena_.get() + (size_t)k * kAnyStride;
+            uint32_t* const pk = packed_.get() + k * 256;
+            for (int b = 0; b < 256; b++) {
+                if (m.tab[b].sy) memset(lk + m.tab[b].lt, b, m.tab[b].sy);
+                pk[b] = m.tab[b].lt | (((uint32_t)b == m.top ? 0u : m.tab[b].sy) << 16);
+            }
+            memset(lk + m.bs, (int)m.top, kAnyStride - m.bs);  // low / help can exceed tot - 1 by a few hundred (decode_symbols)
+        }
+        if (!vb.active) return;
+        for (int k = 0; k < kCap; k++)
+            if (!(vb.active >> k & 1)) { vb.low[k] = 0; vb.range[k] = 0; vb.ptr[k] = nullptr; vb.dst[k] = nullptr; }
+        vec_decode_block_any(&vb);
+        for (int k = 0; k < count_; k++) {
+            if (!vec[k]) continue;
+            Dec& d = *ds_[k];
+            d.low = vb.low[k]; d.range = vb.range[k]; d.pos = (size_t)(vb.ptr[k] - d.in); d.held = vb.ptr[k][-1];
+            produced_[k] += kBlock;
+        }
+    }
 
-private:
     template <class OnEnd>
     void retire(int k, OnEnd on_end)
     {
@@ -1073,6 +1130,10 @@ private:
         tails_[last].clear();
     }
 
+    struct FreeDeleter { void operator()(void* p) const { free(p); } };
+    const bool any_;
+    std::unique_ptr<uint8_t, FreeDeleter> arena_;    // any_: [kCap][kAnyStride] symbol of every cumulative frequency
+    std::unique_ptr<uint32_t, FreeDeleter> packed_;  // any_: [kCap][256] lt | sy << 16
     int count_ = 0;
     std::vector<BlockModel> models_;
     BlockModel* ms_[kCap];
@@ -1092,10 +1153,10 @@ private:
 // `count` streams of dominant-symbol planes (any lengths) on the calling thread through the 16-lane loop: test
 // and measurement hook; the coder pool is the product path.  False if the CPU lacks AVX-512.
 bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced,
-                       const PlaneWindow* const* io)
+                       const PlaneWindow* const* io, bool any)
 {
     if (!vec_available()) return false;
-    std::unique_ptr<VecDecGroup> g(new VecDecGroup);
+    std::unique_ptr<VecDecGroup> g(new VecDecGroup(any));
     int next = 0;
     while (next < count || g->count()) {
         while (next < count && !g->full()) {
@@ -1176,7 +1237,9 @@ public:
             // encoder (opt-in): every plane takes the vector loop (candidate compares while all lanes of a session hold
             // dominant-symbol blocks, gathers from the lanes' tables otherwise)
             const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock;
-            (vec ? vec_q_ : venc ? venc_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
+            // the other decoder planes (noise: ~7 bits per symbol): the 16-lane loop for planes of any statistics
+            const bool vany = jobs[i].kind == PlaneJob::kDecode && !vec && vec_ok_ && vec_any_ && jobs[i].n >= 4 * (size_t)kBlock;
+            (vec ? vec_q_ : venc ? venc_q_ : vany ? vany_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
         if (count > 1) cv_.notify_all(); else cv_.notify_one();
@@ -1185,7 +1248,7 @@ public:
     ~Pool() { resize(0, 0); }
 
 private:
-    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2, kVecEnc = 3 };
+    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2, kVecEnc = 3, kVecAny = 4 };
     // kAny: vector-decode jobs first (one worker absorbs up to 16 of them), then decode, then encode
     PlaneJob* pop(bool block, int want, int* got = nullptr)
     {
@@ -1199,6 +1262,10 @@ private:
             if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
             if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max()) {
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
+            }
+            if (want == kVecAny && !vany_q_.empty()) { PlaneJob* j = vany_q_.front(); vany_q_.pop_front(); return j; }
+            if (want == kAny && !vany_q_.empty() && vany_sessions_ < vany_sessions_max()) {
+                PlaneJob* j = vany_q_.front(); vany_q_.pop_front(); vany_sessions_++; if (got) *got = kVecAny; return j;
             }
             if (want == kVecEnc && !venc_q_.empty()) { PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); return j; }
             if (want == kAny && !venc_q_.empty() && venc_sessions_ < venc_sessions_max()) {
@@ -1216,12 +1283,12 @@ public:
     double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
     // per loop kind (scalar encoder, scalar decoder, vector decoder, vector encoder): worker seconds spent in its block
     // steps and stream-blocks (60000 symbols each, the last block of a stream counted whole) they advanced
-    void loop_stats(double seconds[4], double blocks[4])
+    void loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds])
     {
-        for (int k = 0; k < 4; k++) { seconds[k] = loop_ns_[k].load() * 1e-9; blocks[k] = (double)loop_blocks_[k].load(); }
+        for (int k = 0; k < kLoopKinds; k++) { seconds[k] = loop_ns_[k].load() * 1e-9; blocks[k] = (double)loop_blocks_[k].load(); }
     }
 private:
-    std::atomic<unsigned long long> loop_ns_[4] = {}, loop_blocks_[4] = {};
+    std::atomic<unsigned long long> loop_ns_[kLoopKinds] = {}, loop_blocks_[kLoopKinds] = {};
     void account(int kind, double s, int nstreams)
     {
         loop_ns_[kind] += (unsigned long long)(s * 1e9);
@@ -1242,7 +1309,7 @@ private:
         int dec_streams;
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
         std::unique_ptr<DecGroup> dg;
-        std::unique_ptr<VecDecGroup> vg;
+        std::unique_ptr<VecDecGroup> vg, vag;
         std::unique_ptr<VecEncGroup> veg;
         EncGroup eg;
         struct Tag { PlaneJob* job; double t0; };
@@ -1269,6 +1336,20 @@ private:
                 }
                 { std::lock_guard<std::mutex> lk(mu_); vec_sessions_--; }
                 cv_.notify_all();  // vector jobs queued meanwhile may start a session of their own now
+            } else if (kind == kVecAny) {
+                if (!vag) vag.reset(new VecDecGroup(true));
+                while (j || vag->count()) {
+                    while (j) {
+                        Tag* t = free_tag();
+                        t->job = j; t->t0 = now_s();
+                        vag->add(j->src, j->src_len, j->dst, j->n, t, j->io);
+                        j = vag->full() ? nullptr : pop(false, kVecAny);
+                    }
+                    { const int nstreams = vag->count(); const double ts = now_s(); vag->step(on_end); account(4, now_s() - ts, nstreams); }
+                    if (!vag->full()) j = pop(false, kVecAny);
+                }
+                { std::lock_guard<std::mutex> lk(mu_); vany_sessions_--; }
+                cv_.notify_all();
             } else if (kind == kVecEnc) {
                 if (!veg) veg.reset(new VecEncGroup);
                 while (j || veg->count()) {
@@ -1312,7 +1393,22 @@ private:
 
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_;
+    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_, vany_q_;
+    // WR_VEC_ANY=1: decoder planes without dominant symbols (noise planes) take the 16-lane loop for planes of any
+    // statistics instead of the scalar loops of up to four; WR_VEC_ANY_SESSIONS workers at most run such a session at a
+    // time (default: an eighth of the workers, at least one).  Opt-in: EPYC 9575F, one thread, noise planes: 438 Msym/s
+    // with 16 lanes against 323 in the scalar loop of four, but every stream in it advances at 27 Msym/s against 81
+    // (profiles/r03/h_rc_any_epyc9575f.txt), and with the fields in flight bounded by memory it is the slowest stream of
+    // a field that sets the rate.
+    const bool vec_any_ = getenv("WR_VEC_ANY") && atoi(getenv("WR_VEC_ANY"));
+    int vany_sessions_ = 0;
+    const int vany_sessions_env_ = getenv("WR_VEC_ANY_SESSIONS") ? atoi(getenv("WR_VEC_ANY_SESSIONS")) : 0;
+    int vany_sessions_max() const  // call with mu_ held
+    {
+        if (vany_sessions_env_ > 0) return vany_sessions_env_;
+        const int w = (int)workers_.size();
+        return w < 8 ? 1 : (w + 4) / 8;
+    }
     // The encoder's vector loop takes every plane (WR_VEC_ENCODE=0: scalar loops of three instead): 16 planes at 1.0-1.3
     // Gsym/s per worker in the pipeline against 0.56 in the scalar loops.  Per stream it advances at 75-150 Msym/s against
     // ~190, so the sessions are kept as many as leave a field's encode no longer than its decode (WR_VEC_ENC_SESSIONS;
@@ -1345,7 +1441,7 @@ private:
 void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
-void pool_loop_stats(double seconds[4], double blocks[4]) { Pool::get().loop_stats(seconds, blocks); }
+void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]) { Pool::get().loop_stats(seconds, blocks); }
 bool pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { return Pool::get().submit(jobs, count, batch); }
 void pool_wait(JobBatch* batch)
 {

@@ -54,8 +54,10 @@ void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8
 
 // `count` dominant-symbol planes (any lengths) on the calling thread, up to 16 at a time in the AVX-512 loop
 // (wr_rangecoder_vec.h); false if the CPU lacks AVX-512.  Same symbols as decode_plane on each.
+// any: through the loop for planes of any statistics (division and table look-ups per lane: what noise planes need)
+// instead of the candidate-compare loop.
 bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced,
-                       const PlaneWindow* const* io = nullptr);
+                       const PlaneWindow* const* io = nullptr, bool any = false);
 
 // `count` planes of any kind on the calling thread, up to 16 at a time in the AVX-512 encoder loop; false if the CPU
 // lacks AVX-512.  Same bytes as encode_plane on each.
@@ -86,7 +88,9 @@ struct PlaneJob {
 };
 void pool_configure(int nthreads, int dec_streams);  // nthreads = 0 stops the pool; dec_streams < 1 keeps the setting
 int pool_threads();
-void pool_loop_stats(double seconds[4], double blocks[4]);  // per loop kind {scalar enc, scalar dec, vector dec, vector enc}: worker seconds in block steps, stream-blocks advanced
+constexpr int kLoopKinds = 5;
+// per loop kind {scalar enc, scalar dec, vector dec (dominant symbols), vector enc, vector dec (any statistics)}: worker seconds in block steps, stream-blocks advanced
+void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]);
 double pool_idle_seconds();  // time the workers have spent waiting for a job since the process started, summed over workers
 // The jobs must stay valid until pool_wait returns.  False (nothing queued) if the pool has no workers -- it may have
 // been stopped by another thread since the caller looked at pool_threads(): the caller then codes the planes itself.

@@ -152,6 +152,130 @@ void vec_decode_block(VecBlock* b, VecOther other)
         if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
 }
 
+void vec_decode_block_any(VecAnyBlock* b)
+{
+    const __mmask16 act = (__mmask16)b->active;
+    const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
+    __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
+    __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
+    const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
+    const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
+    const __m512i lo16 = _mm512_set1_epi32(0xffff);
+    const uint8_t* const lookup = b->lookup;
+    uint32_t* const packed = b->packed;
+    // idle lanes: low stays 0, so their cumulative frequency is 0; entry 0 = {lt 0, sy 60000} keeps their range where it
+    // is (range / 60000 * 60000 is a fixed point after the first step) and above Bottom: they never renormalise
+    for (int j = 0; j < kVecLanes; j++)
+        if (!(act >> j & 1)) { b->lookup[(size_t)j * kAnyStride] = 0; packed[j * 256] = kBlockSyms << 16; }
+
+    // byte feed: as in vec_decode_block
+    const uint8_t* pw[kVecLanes];
+    uint8_t* d[kVecLanes];
+    alignas(64) uint32_t w0[kVecLanes], w1[kVecLanes];
+    auto window_at = [](const uint8_t* q) -> uint32_t {
+        uint64_t v;
+        __builtin_memcpy(&v, q - 1, 8);
+        return (uint32_t)(__builtin_bswap64(v) >> 25);
+    };
+    for (int j = 0; j < kVecLanes; j++) {
+        pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = w1[j] = 0;
+        if (act >> j & 1) { w0[j] = window_at(pw[j]); w1[j] = window_at(pw[j] + 4); }
+    }
+    __m512i win = _mm512_load_si512(w0), nxt = _mm512_load_si512(w1);
+    __m512i cnt = _mm512_set1_epi32(4);
+    const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
+    alignas(64) uint32_t cfb[kVecLanes];
+    alignas(64) uint8_t stage[kVecLanes][64];  // the last (up to) 64 symbols of every lane
+
+    for (uint32_t i = 0; i < kBlockSyms; i++) {
+        // ---- renormalise (rangecod.c:294-302)
+        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
+        while (sh) {  // noise planes: some lane shifts in nearly every step; a second byte: symbol probability < 1/256
+            low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
+            range = _mm512_mask_slli_epi32(range, sh, range, 8);
+            win = _mm512_mask_slli_epi32(win, sh, win, 8);
+            cnt = _mm512_mask_sub_epi32(cnt, sh, cnt, one);
+            const __mmask16 dry = _mm512_cmpeq_epu32_mask(cnt, _mm512_setzero_si512());
+            if (dry) {
+                win = _mm512_mask_mov_epi32(win, dry, nxt);
+                cnt = _mm512_mask_mov_epi32(cnt, dry, four);
+                unsigned m = dry & act;
+                while (m) {
+                    const int j = __builtin_ctz(m);
+                    m &= m - 1;
+                    pw[j] += 4;
+                    nxt = _mm512_mask_set1_epi32(nxt, (__mmask16)(1u << j), (int)window_at(pw[j] + 4));
+                }
+            }
+            sh = _mm512_cmple_epu32_mask(range, vbottom);
+        }
+        // ---- help = range / 60000 (rangecod.c:312)
+        const __m512i n5 = _mm512_srli_epi32(range, 5);
+        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
+        const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
+        const __m512i help = _mm512_or_si512(ev, od);
+        // ---- cf = low / help (rangecod.c:313) in double precision, truncated.  Exact: low < 2^32 and help < 2^16 (range <=
+        // 2^31, / 60000) are doubles as they stand; the quotient x = low / help is below 2^32, and when it is not an integer
+        // it lies at least 1 / help >= 2^-16 away from one, while the correctly rounded double quotient is within
+        // 2^-53 x < 2^-21 of x: rounding never reaches the next integer, so the truncation is floor(low / help).
+        const __m256i q0 = _mm512_cvttpd_epu32(_mm512_div_pd(_mm512_cvtepu32_pd(_mm512_castsi512_si256(low)),
+                                                             _mm512_cvtepu32_pd(_mm512_castsi512_si256(help))));
+        const __m256i q1 = _mm512_cvttpd_epu32(_mm512_div_pd(_mm512_cvtepu32_pd(_mm512_extracti64x4_epi64(low, 1)),
+                                                             _mm512_cvtepu32_pd(_mm512_extracti64x4_epi64(help, 1))));
+        _mm256_store_si256(reinterpret_cast<__m256i*>(cfb), q0);
+        _mm256_store_si256(reinterpret_cast<__m256i*>(cfb + 8), q1);
+        // ---- the symbol of cf and its {lt, sy}: two dependent loads per lane; the symbol goes to the lane's staging row,
+        // the packed entry into a vector by inserts (sixteen narrow stores read back by one wide load would have to
+        // wait for the stores to retire)
+        const uint32_t col = i & 63;
+        __m128i x[4];
+#pragma GCC unroll 4
+        for (int g = 0; g < 4; g++) {
+            uint32_t e[4];
+#pragma GCC unroll 4
+            for (int k = 0; k < 4; k++) {
+                const int j = 4 * g + k;
+                const uint32_t c = lookup[(size_t)j * kAnyStride + cfb[j]];
+                stage[j][col] = (uint8_t)c;
+                e[k] = packed[j * 256 + c];
+            }
+            x[g] = _mm_insert_epi32(_mm_insert_epi32(_mm_insert_epi32(_mm_cvtsi32_si128((int)e[0]), (int)e[1], 1), (int)e[2], 2), (int)e[3], 3);
+        }
+        const __m512i ent = _mm512_inserti64x4(_mm512_castsi256_si512(_mm256_inserti128_si256(_mm256_castsi128_si256(x[0]), x[1], 1)),
+                                               _mm256_inserti128_si256(_mm256_castsi128_si256(x[2]), x[3], 1), 1);
+        // ---- rangecod.c:339-351: low -= help * lt; range = help * sy, or what is left of it for the largest symbol
+        const __m512i lt = _mm512_and_si512(ent, lo16), sy = _mm512_srli_epi32(ent, 16);
+        const __m512i t = _mm512_mullo_epi32(help, lt);
+        const __mmask16 is_top = _mm512_cmpeq_epu32_mask(sy, _mm512_setzero_si512());
+        low = _mm512_sub_epi32(low, t);
+        range = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy), is_top, range, t);
+        // ---- symbols out: 64 per lane at a time
+        if (col == 63) {
+            unsigned m = act;
+            while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                _mm512_storeu_si512(d[j] + (i - 63), _mm512_load_si512(stage[j]));
+            }
+        }
+    }
+    {   // 60000 = 937 * 64 + 32: the last 32 symbols of every lane
+        constexpr uint32_t done = kBlockSyms / 64 * 64, rest = kBlockSyms - done;
+        unsigned m = act;
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            memcpy(d[j] + done, stage[j], rest);
+        }
+    }
+    _mm512_mask_storeu_epi32(b->low, act, low);
+    _mm512_mask_storeu_epi32(b->range, act, range);
+    alignas(64) uint32_t left[kVecLanes];
+    _mm512_store_si512(left, cnt);
+    for (int j = 0; j < kVecLanes; j++)
+        if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
+}
+
 template <bool ALWAYS, bool GATHER>
 static void vec_encode_block_t(VecEncBlock* b)
 {

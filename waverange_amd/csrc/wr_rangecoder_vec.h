@@ -49,6 +49,25 @@ struct VecEncBlock {
 };
 void vec_encode_block(VecEncBlock* b);
 
+// One full block (60000 symbols) of up to 16 decoder streams with ANY statistics (noise planes: ~7 bits per symbol, no
+// dominant symbols to compare with).  The step needs the reference's two divisions (rangecod.c:312-313): range / 60000
+// is a multiply-shift, low / help is done in double precision, 8 lanes per vdivpd -- exact, see the proof at the loop --
+// and its two table look-ups (symbol of a cumulative frequency, then {lt, sy} of the symbol), which stay scalar loads per
+// lane (the 60 KB tables of 16 lanes are 1 MB: they live in L2; AMD's gathers are microcoded and slower than 16 loads)
+// whose results return to a vector by inserts, not through memory.  ~9 instructions per symbol against ~35 in the
+// scalar loop of four (wr_rangecoder.cpp, decode_symbols_multi).
+constexpr uint32_t kAnyStride = 60544;  // kBlock + 512 (see decode_symbols: cf < tot + 430) rounded up to 64
+struct VecAnyBlock {
+    uint32_t active;                 // lane mask
+    uint32_t low[kVecLanes], range[kVecLanes];
+    const uint8_t* ptr[kVecLanes];   // next unread stream byte; ptr[-1] is the byte held back (rangecod.c:297-299)
+    uint8_t* dst[kVecLanes];         // 60000 symbols each
+    uint8_t* lookup;                 // [16][kAnyStride]: symbol of every cumulative frequency, padded with the largest symbol
+    uint32_t* packed;                // [16][256]: lt | sy << 16, sy = 0 marking the largest symbol present (open-ended
+                                     // interval, rangecod.c:345-348); entry 0 of idle lanes is overwritten
+};
+void vec_decode_block_any(VecAnyBlock* b);
+
 bool vec_available();  // the CPU has AVX-512 F/BW/DQ/VL and WR_NO_AVX512 is not set
 void vec_decode_block(VecBlock* b, VecOther other);
 
