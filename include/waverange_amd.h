@@ -171,6 +171,8 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_SLOTS_POPULATED 1 /* work-space slots that received device buffers */
 #define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
 #define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */
+#define WR_STAT_POOL_STREAMS_MOVED 4  /* plane streams that changed pool workers between two blocks: an idle worker takes over half
+                                        of the streams of the fullest running session (WR_POOL_STEAL=0 turns that off) */
 unsigned long wr_stat(int what);
 /* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder,
  * 16-lane decoder for planes of any statistics} -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block

@@ -140,6 +140,41 @@ int main() {
         }
         wrrc::pool_configure(0, 0);
     }
+    // streams changing workers: long planes of every kind submitted at once to a pool of five -- the first workers take
+    // them all into 16-lane sessions, the idle ones take over halves at block boundaries (Pool::offer / next)
+    {
+        const int count = 22;
+        const size_t n = (size_t)60000 * 9 + 1234;
+        std::vector<std::vector<uint8_t>> p(count), enc(count), out2(count), back2(count);
+        std::vector<size_t> len(count);
+        for (int k = 0; k < count; k++) {
+            p[k].resize(n);
+            for (size_t i = 0; i < n; i++) { unsigned r = rnd(); p[k][i] = k % 3 == 0 ? r & 255 : k % 3 == 1 ? ((r & 7) ? 254 : 255) : ((r & 1023) ? 7 : r >> 12 & 255); }
+            std::vector<uint8_t> o(wrrc::encode_bound(n));
+            len[k] = wrrc::encode_plane(p[k].data(), n, o.data(), nullptr);
+            enc[k].assign(o.begin(), o.begin() + len[k]);
+        }
+        const unsigned long moved0 = wrrc::pool_streams_moved();
+        wrrc::pool_configure(5, 4);
+        for (int rep = 0; rep < 3; rep++) {
+            std::vector<wrrc::PlaneJob> jobs(2 * count);
+            wrrc::JobBatch batch;
+            for (int k = 0; k < count; k++) {
+                out2[k].assign(wrrc::encode_bound(n), 0); back2[k].assign(n, 0xEE);
+                jobs[k].kind = wrrc::PlaneJob::kEncode; jobs[k].src = p[k].data(); jobs[k].n = n; jobs[k].dst = out2[k].data();
+                jobs[count + k].kind = wrrc::PlaneJob::kDecode; jobs[count + k].src = enc[k].data(); jobs[count + k].src_len = len[k];
+                jobs[count + k].dst = back2[k].data(); jobs[count + k].n = n;
+            }
+            if (!wrrc::pool_submit(jobs.data(), 2 * count, &batch)) { printf("pool refused the jobs\n"); return 1; }
+            wrrc::pool_wait(&batch);
+            for (int k = 0; k < count; k++) {
+                if (jobs[k].result != len[k] || memcmp(out2[k].data(), enc[k].data(), len[k])) { printf("moved streams: pool encode differs k=%d\n", k); return 1; }
+                if (jobs[count + k].result != n || memcmp(back2[k].data(), p[k].data(), n)) { printf("moved streams: pool decode failed k=%d\n", k); return 1; }
+            }
+        }
+        wrrc::pool_configure(0, 0);
+        printf("streams that changed workers: %lu\n", wrrc::pool_streams_moved() - moved0);
+    }
     // windowed symbol access (PlaneWindow): exact-size window buffers allocated afresh for every window, so ASan sees
     // any access outside the window or to a window that was handed back
     {

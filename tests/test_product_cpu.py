@@ -342,3 +342,43 @@ def test_windowed_symbol_access_same_bytes_as_oracle(oracle, n):
                     assert got[i] == n and np.array_equal(dec[i], planes[i]), ("healthy next to damaged", mode, i)
     finally:
         api.set_coder_pool(0)
+
+
+def test_streams_change_workers_same_bytes(oracle):
+    """The coder pool's idle workers take over half of the streams of the fullest session at a block boundary (wr_rangecoder.cpp,
+    Pool::offer / next).  Many long planes submitted at once to a pool whose first worker grabs them all into one 16-lane
+    session: the other workers must end up with streams (the counter moves) and every stream and every decoded plane must
+    equal the oracle's -- encoder sessions, decoder sessions of both kinds, whole planes and windowed ones."""
+    from waverange_amd import api
+    rs = np.random.RandomState(11)
+    n = 60000 * 12 + 4321
+    planes = []
+    for k in range(14):
+        if k % 3 == 0:
+            planes.append(rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.8, 0.2]))
+        elif k % 3 == 1:
+            planes.append(np.where(rs.random_sample(n) < 0.999, 255, rs.randint(0, 256, n)).astype(np.uint8))
+        else:
+            planes.append(rs.randint(0, 256, n).astype(np.uint8))
+    want = [oracle.range_encode(p) for p in planes]
+    api.set_coder_pool(4, 4)
+    try:
+        before = api.stat(api.STAT_POOL_STREAMS_MOVED)
+        for rep in range(3):
+            enc = api.range_encode_pool(planes)
+            for i, (a, b) in enumerate(zip(enc, want)):
+                assert np.array_equal(a, b), ("encode", rep, i)
+            dec, got = api.range_decode_pool(want, [n] * len(planes))
+            for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+                assert g == n and np.array_equal(d, p), ("decode", rep, i)
+            enc = api.range_encode_windowed(planes, 120000, 1)
+            for i, (a, b) in enumerate(zip(enc, want)):
+                assert np.array_equal(a, b), ("windowed encode", rep, i)
+            dec, got = api.range_decode_windowed(want, n, 120000, 1)
+            for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+                assert g == n and np.array_equal(d, p), ("windowed decode", rep, i)
+        moved = api.stat(api.STAT_POOL_STREAMS_MOVED) - before
+        if api.lib().wr_range_decode_vec(0, None, None, None, None, None) == 0:   # AVX-512 sessions exist on this CPU
+            assert moved > 0, "no stream ever changed workers"
+    finally:
+        api.set_coder_pool(0)

@@ -181,7 +181,7 @@ def set_device_slots(device, nslots):
     _check(lib().wr_set_device_slots(int(device), int(nslots)))
 
 
-STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDLE_MS = 0, 1, 2, 3
+STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDLE_MS, STAT_POOL_STREAMS_MOVED = 0, 1, 2, 3, 4
 
 
 def stat(what):

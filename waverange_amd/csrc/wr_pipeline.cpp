@@ -402,6 +402,7 @@ void wr_pool_loop_stats(double* seconds, double* blocks) { wrrc::pool_loop_stats
 unsigned long wr_stat(int what)
 {
     if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
+    if (what == WR_STAT_POOL_STREAMS_MOVED) return wrrc::pool_streams_moved();
     return (what >= 0 && what < 4) ? g_stat[what].load() : 0;
 }
 void wr_set_coder_pool(int nthreads, int decoder_streams)

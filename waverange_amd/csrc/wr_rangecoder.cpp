@@ -370,6 +370,13 @@ private:
 
 namespace {
 
+// An encoder stream between two blocks, as it moves from one worker's session to another's (Pool: an idle worker takes
+// over half of the streams of the fullest session)
+struct EncStream {
+    Enc e;
+    EncGroup::Stream st;
+};
+
 // Up to 16 encoder streams advancing block by block in lockstep on one thread: the full blocks that at most four
 // symbols hold (>= 99 %) are coded 16 lanes at a time by the AVX-512 loop (wr_rangecoder_vec.h), block headers,
 // other blocks and the final partial block by the scalar code of their stream.
@@ -386,6 +393,20 @@ public:
         st_[k] = EncGroup::Stream{SymCursor(), n, 0, 0, hist, tag};
         st_[k].sym.set(sym, n, io);
     }
+    // hand the last stream over (call between steps) / adopt one
+    EncStream give()
+    {
+        const int k = --count_;
+        return EncStream{*es_[k], st_[k]};
+    }
+    void take(const EncStream& m)
+    {
+        const int k = count_++;
+        es_[k] = new (store_[k]) Enc(m.e);
+        st_[k] = m.st;
+    }
+    void* tag_of_last() const { return st_[count_ - 1].tag; }
+    void set_tag_of_last(void* t) { st_[count_ - 1].tag = t; }
     template <class OnEnd>
     void step(OnEnd on_end)
     {
@@ -817,6 +838,17 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
 
 namespace {
 
+// A decoder stream between two blocks, as it moves from one worker's session to another's.  `d.in` may point into
+// `tail` (the zero-padded copy of the stream's end): moving the vector keeps its buffer where it is.
+struct DecStream {
+    Dec d;
+    SymCursor cur;
+    size_t n, produced;
+    bool failed;
+    void* tag;
+    std::vector<uint8_t> tail;
+};
+
 // Slow-path block of one stream (partial block, window or stream about to end): decoded straight into what is left
 // of the stream's window, or -- a block that straddles the end of a window although the plane goes on, which only
 // happens behind a block of fewer than 60000 symbols in mid-stream: the reference's encoder never writes one, the
@@ -858,6 +890,22 @@ public:
         cur_[k].set(sym, n, io); n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
         tails_[k].clear();
     }
+    // hand the last stream over (call between steps) / adopt one
+    DecStream give()
+    {
+        const int k = --count_;
+        DecStream m{*ds_[k], cur_[k], n_[k], produced_[k], failed_[k], tag_[k], std::move(tails_[k])};
+        tails_[k].clear();
+        return m;
+    }
+    void take(DecStream&& m)
+    {
+        const int k = count_++;
+        ds_[k] = new (store_[k]) Dec(m.d);
+        cur_[k] = m.cur; n_[k] = m.n; produced_[k] = m.produced; failed_[k] = m.failed; tag_[k] = m.tag;
+        tails_[k] = std::move(m.tail);
+    }
+    void set_tag_of_last(void* t) { tag_[count_ - 1] = t; }
     // one block of every stream; on_end(tag, symbols the stream held or (size_t)-1) for the streams that ended
     template <class OnEnd>
     void step(OnEnd on_end)
@@ -990,6 +1038,21 @@ public:
         cur_[k].set(sym, n, io); n_[k] = n; produced_[k] = 0; failed_[k] = false; tag_[k] = tag;
         tails_[k].clear();
     }
+    DecStream give()
+    {
+        const int k = --count_;
+        DecStream m{*ds_[k], cur_[k], n_[k], produced_[k], failed_[k], tag_[k], std::move(tails_[k])};
+        tails_[k].clear();
+        return m;
+    }
+    void take(DecStream&& m)
+    {
+        const int k = count_++;
+        ds_[k] = new (store_[k]) Dec(m.d);
+        cur_[k] = m.cur; n_[k] = m.n; produced_[k] = m.produced; failed_[k] = m.failed; tag_[k] = m.tag;
+        tails_[k] = std::move(m.tail);
+    }
+    void set_tag_of_last(void* t) { tag_[count_ - 1] = t; }
     template <class OnEnd>
     void step(OnEnd on_end)
     {
@@ -1221,7 +1284,8 @@ public:
         for (auto& t : old) t.join();
         lk.lock();
         stop_ = false;
-        for (int i = 0; i < nthreads; i++) workers_.emplace_back([this] { run(); });
+        lanes_.assign((size_t)nthreads, 0);
+        for (int i = 0; i < nthreads; i++) workers_.emplace_back([this, i] { run(i); });
     }
     // false: the pool has no workers (never started, or stopped meanwhile by another thread) -- nothing was queued and
     // the caller codes the planes itself
@@ -1281,6 +1345,7 @@ private:
     }
 public:
     double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
+    unsigned long streams_moved() { return moved_.load(); }
     // per loop kind (scalar encoder, scalar decoder, vector decoder, vector encoder): worker seconds spent in its block
     // steps and stream-blocks (60000 symbols each, the last block of a stream counted whole) they advanced
     void loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds])
@@ -1304,7 +1369,106 @@ private:
         if (--b->remaining == 0) b->cv.notify_all();
     }
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    void run()
+
+    // ---- streams change workers.  The fields in flight are bounded by memory, so what sets the whole-job rate is how fast
+    // the slowest plane stream of every field advances, and a stream advances the faster the fewer streams share its
+    // worker's loop.  A worker that finds nothing queued therefore takes over half of the streams of the fullest running
+    // session, at that session's next block boundary (every 60000 symbols per stream: a millisecond or so): the session's
+    // owner packs them up (offer), the idle worker adopts them (next) -- same kind of loop, same bytes, the streams only
+    // change threads between two blocks.  WR_POOL_STEAL=0 turns it off.
+    struct Tag { PlaneJob* job; double t0; };
+    struct Handoff {
+        int kind = kAny;
+        std::vector<DecStream> dec;
+        std::vector<EncStream> enc;
+        std::vector<Tag> tags;  // job and start time of every stream, in the same order
+        bool empty() const { return dec.empty() && enc.empty(); }
+    };
+    std::deque<Handoff> handoff_;
+    int thieves_ = 0;            // workers waiting with nothing queued for them (mu_)
+    std::vector<int> lanes_;     // streams in every worker's running session, by worker index (mu_)
+    const bool steal_ = !(getenv("WR_POOL_STEAL") && !atoi(getenv("WR_POOL_STEAL")));
+    std::atomic<unsigned long> moved_{0};
+
+    // what a worker does next: a queued job (*j, the session kind in *kind) or streams handed over by another worker (*h);
+    // false: the pool is stopping and nothing is left
+    bool next(int* kind, PlaneJob** j, Handoff* h)
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            if (!handoff_.empty()) { *h = std::move(handoff_.front()); handoff_.pop_front(); *kind = h->kind; *j = nullptr; return true; }
+        }
+        for (;;) {
+            *j = pop(false, kAny, kind);
+            if (*j) return true;
+            std::unique_lock<std::mutex> lk(mu_);
+            if (!handoff_.empty()) { *h = std::move(handoff_.front()); handoff_.pop_front(); *kind = h->kind; return true; }
+            if (!(vec_q_.empty() && venc_q_.empty() && vany_q_.empty() && dec_q_.empty() && enc_q_.empty()) && startable()) continue;
+            if (stop_) return false;
+            const double t = now_s();
+            thieves_++;
+            cv_.wait(lk);
+            thieves_--;
+            idle_s_ += now_s() - t;
+        }
+    }
+    // something queued that a worker without a session may start now (mu_ held)
+    bool startable() const
+    {
+        return (!vec_q_.empty() && vec_sessions_ < vec_sessions_max()) || (!vany_q_.empty() && vany_sessions_ < vany_sessions_max()) ||
+               (!venc_q_.empty() && venc_sessions_ < venc_sessions_max()) || !dec_q_.empty() || !enc_q_.empty();
+    }
+    // A session's owner, between two blocks: publishes how many streams it holds and, if a worker is waiting and no
+    // session is fuller, hands over half of them.
+    template <class G, class Pack>
+    void offer(int id, int kind, G& g, Pack pack)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        lanes_[(size_t)id] = g.count();
+        if (!steal_ || thieves_ <= (int)handoff_.size() || g.count() < 2) return;
+        for (int c : lanes_) if (c > g.count()) return;  // a fuller session does it at its next boundary
+        Handoff h;
+        h.kind = kind;
+        for (int k = g.count() / 2; k > 0; k--) pack(g, &h);
+        if (h.tags.empty()) return;  // (a kind whose streams stay put)
+        lanes_[(size_t)id] = g.count();
+        moved_ += (unsigned long)h.tags.size();
+        handoff_.push_back(std::move(h));
+        cv_.notify_one();
+    }
+    void session_over(int id, int* counter)
+    {
+        { std::lock_guard<std::mutex> lk(mu_); lanes_[(size_t)id] = 0; if (counter) (*counter)--; }
+        if (counter) cv_.notify_all();  // jobs of that kind queued meanwhile may start a session of their own now
+    }
+
+    // One session: the streams of one kind this worker interleaves, topped up from the kind's queue and thinned out by
+    // offer() at block boundaries.  Starts with one queued job or with the streams of a hand-over.
+    template <class G, class Add, class Adopt, class Pack>
+    void session(int id, int kind, int stat, G& g, PlaneJob* j, Handoff& h, Tag* tags, Add add, Adopt adopt, Pack pack)
+    {
+        auto free_tag = [&]() -> Tag* { for (int i = 0; i < kVecLanes; i++) if (!tags[i].job) return &tags[i]; return nullptr; };
+        auto on_end = [](void* tag, size_t result) { Tag* t = static_cast<Tag*>(tag); finish(t->job, result, t->t0); t->job = nullptr; };
+        for (size_t i = 0; i < h.tags.size(); i++) {
+            Tag* t = free_tag();
+            *t = h.tags[i];
+            adopt(g, h, i, t);
+        }
+        h = Handoff();
+        while (j || g.count()) {
+            while (j) {
+                Tag* t = free_tag();
+                t->job = j; t->t0 = now_s();
+                add(g, j, t);
+                j = g.full() ? nullptr : pop(false, kind);
+            }
+            { const int nstreams = g.count(); const double ts = now_s(); g.step(on_end); account(stat, now_s() - ts, nstreams); }
+            offer(id, kind, g, pack);
+            if (!g.full()) j = pop(false, kind);
+        }
+    }
+
+    void run(int id)
     {
         int dec_streams;
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
@@ -1312,81 +1476,51 @@ private:
         std::unique_ptr<VecDecGroup> vg, vag;
         std::unique_ptr<VecEncGroup> veg;
         EncGroup eg;
-        struct Tag { PlaneJob* job; double t0; };
         Tag tags[kVecLanes];
-        auto free_tag = [&]() -> Tag* { for (Tag& t : tags) if (!t.job) return &t; return nullptr; };
-        auto on_end = [](void* tag, size_t result) { Tag* t = static_cast<Tag*>(tag); finish(t->job, result, t->t0); t->job = nullptr; };
+        auto add_dec = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->src_len, j->dst, j->n, t, j->io); };
+        auto add_enc = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->n, j->dst, j->hist, t, j->io); };
+        auto adopt_dec = [](auto& g, Handoff& h, size_t i, Tag* t) { g.take(std::move(h.dec[i])); g.set_tag_of_last(t); };
+        auto adopt_enc = [](auto& g, Handoff& h, size_t i, Tag* t) { g.take(h.enc[i]); g.set_tag_of_last(t); };
+        auto pack_dec = [](auto& g, Handoff* h) {
+            DecStream m = g.give();
+            Tag* t = static_cast<Tag*>(m.tag);
+            h->tags.push_back(*t); t->job = nullptr;
+            h->dec.push_back(std::move(m));
+        };
+        auto pack_enc = [](auto& g, Handoff* h) {
+            EncStream m = g.give();
+            Tag* t = static_cast<Tag*>(m.st.tag);
+            h->tags.push_back(*t); t->job = nullptr;
+            h->enc.push_back(m);
+        };
+        auto pack_none = [](auto&, Handoff*) {};
         for (;;) {
             int kind = kAny;
-            PlaneJob* j = pop(true, kAny, &kind);
-            if (!j) return;
+            PlaneJob* j = nullptr;
+            Handoff h;
+            if (!next(&kind, &j, &h)) return;
             for (Tag& t : tags) t.job = nullptr;
-            // a session: the streams of one kind this worker interleaves, topped up at block boundaries
+            const bool counted = j != nullptr;  // a session started from a queue counts against its kind's cap (pop)
             if (kind == kVec) {
                 if (!vg) vg.reset(new VecDecGroup);
-                while (j || vg->count()) {
-                    while (j) {
-                        Tag* t = free_tag();
-                        t->job = j; t->t0 = now_s();
-                        vg->add(j->src, j->src_len, j->dst, j->n, t, j->io);
-                        j = vg->full() ? nullptr : pop(false, kVec);
-                    }
-                    { const int nstreams = vg->count(); const double ts = now_s(); vg->step(on_end); account(2, now_s() - ts, nstreams); }
-                    if (!vg->full()) j = pop(false, kVec);
-                }
-                { std::lock_guard<std::mutex> lk(mu_); vec_sessions_--; }
-                cv_.notify_all();  // vector jobs queued meanwhile may start a session of their own now
+                session(id, kVec, 2, *vg, j, h, tags, add_dec, adopt_dec, pack_dec);
+                session_over(id, counted ? &vec_sessions_ : nullptr);
             } else if (kind == kVecAny) {
                 if (!vag) vag.reset(new VecDecGroup(true));
-                while (j || vag->count()) {
-                    while (j) {
-                        Tag* t = free_tag();
-                        t->job = j; t->t0 = now_s();
-                        vag->add(j->src, j->src_len, j->dst, j->n, t, j->io);
-                        j = vag->full() ? nullptr : pop(false, kVecAny);
-                    }
-                    { const int nstreams = vag->count(); const double ts = now_s(); vag->step(on_end); account(4, now_s() - ts, nstreams); }
-                    if (!vag->full()) j = pop(false, kVecAny);
-                }
-                { std::lock_guard<std::mutex> lk(mu_); vany_sessions_--; }
-                cv_.notify_all();
+                session(id, kVecAny, 4, *vag, j, h, tags, add_dec, adopt_dec, pack_dec);
+                session_over(id, counted ? &vany_sessions_ : nullptr);
             } else if (kind == kVecEnc) {
                 if (!veg) veg.reset(new VecEncGroup);
-                while (j || veg->count()) {
-                    while (j) {
-                        Tag* t = free_tag();
-                        t->job = j; t->t0 = now_s();
-                        veg->add(j->src, j->n, j->dst, j->hist, t, j->io);
-                        j = veg->full() ? nullptr : pop(false, kVecEnc);
-                    }
-                    { const int nstreams = veg->count(); const double ts = now_s(); veg->step(on_end); account(3, now_s() - ts, nstreams); }
-                    if (!veg->full()) j = pop(false, kVecEnc);
-                }
-                { std::lock_guard<std::mutex> lk(mu_); venc_sessions_--; }
-                cv_.notify_all();
+                session(id, kVecEnc, 3, *veg, j, h, tags, add_enc, adopt_enc, pack_enc);
+                session_over(id, counted ? &venc_sessions_ : nullptr);
             } else if (kind == kDec) {
                 if (!dg) dg.reset(new DecGroup(dec_streams));
-                while (j || dg->count()) {
-                    while (j) {
-                        Tag* t = free_tag();
-                        t->job = j; t->t0 = now_s();
-                        dg->add(j->src, j->src_len, j->dst, j->n, t, j->io);
-                        j = dg->full() ? nullptr : pop(false, kDec);
-                    }
-                    { const int nstreams = dg->count(); const double ts = now_s(); dg->step(on_end); account(1, now_s() - ts, nstreams); }
-                    if (!dg->full()) j = pop(false, kDec);
-                }
+                session(id, kDec, 1, *dg, j, h, tags, add_dec, adopt_dec, pack_dec);
+                session_over(id, nullptr);
             } else {
-                while (j || eg.count()) {
-                    while (j) {
-                        Tag* t = free_tag();
-                        t->job = j; t->t0 = now_s();
-                        eg.add(j->src, j->n, j->dst, j->hist, t, j->io);
-                        j = eg.full() ? nullptr : pop(false, kEnc);
-                    }
-                    { const int nstreams = eg.count(); const double ts = now_s(); eg.step(on_end); account(0, now_s() - ts, nstreams); }
-                    if (!eg.full()) j = pop(false, kEnc);
-                }
+                // (scalar encoder loops of three: only without AVX-512 or with WR_VEC_ENCODE=0; their streams stay put)
+                session(id, kEnc, 0, eg, j, h, tags, add_enc, [](EncGroup&, Handoff&, size_t, Tag*) {}, pack_none);
+                session_over(id, nullptr);
             }
         }
     }
@@ -1441,6 +1575,7 @@ private:
 void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
+unsigned long pool_streams_moved() { return Pool::get().streams_moved(); }
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]) { Pool::get().loop_stats(seconds, blocks); }
 bool pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { return Pool::get().submit(jobs, count, batch); }
 void pool_wait(JobBatch* batch)

@@ -91,6 +91,7 @@ int pool_threads();
 constexpr int kLoopKinds = 5;
 // per loop kind {scalar enc, scalar dec, vector dec (dominant symbols), vector enc, vector dec (any statistics)}: worker seconds in block steps, stream-blocks advanced
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]);
+unsigned long pool_streams_moved();  // streams that changed workers between two blocks (an idle worker took over half of the fullest session)
 double pool_idle_seconds();  // time the workers have spent waiting for a job since the process started, summed over workers
 // The jobs must stay valid until pool_wait returns.  False (nothing queued) if the pool has no workers -- it may have
 // been stopped by another thread since the caller looked at pool_threads(): the caller then codes the planes itself.
