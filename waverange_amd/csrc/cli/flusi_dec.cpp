@@ -38,7 +38,10 @@ int main(int argc, char** argv)
     if (!flusi::get_params(argc, argv, false, keys, prompts,
                            "usage: ./wrdec compressed_000.h5 decompressed_000.h5 TYPE PRECISION\n"
                            "where TYPE=(0: regular output; 1: backup) and PRECISION=(1:single; 2:double)\n"
-                           "interactive mode if not enough arguments are passed.\n", p))
+                           "interactive mode if not enough arguments are passed.\n"
+                           "note: the HDF5 container layout follows the sources of the reference's FluSI tools (src/flusi); it could not be\n"
+                           "      compared with files written by them (they do not compile with current g++ and ship no sample files): the coded\n"
+                           "      bytes and coding attributes inside are bit-identical to the reference codec's, the container itself is unpinned.\n", p))
         return -1;
     int file_type = 0, outtype = 1;  // main_dec.cpp:66 defaults
     std::stringstream(p[2]) >> file_type;

@@ -42,7 +42,10 @@ int main(int argc, char** argv)
     if (!flusi::get_params(argc, argv, true, keys, prompts,
                            "usage: ./wrenc original_000.h5 compressed_000.h5 TYPE TOLERANCE\n"
                            "where TYPE=(0: regular output; 1: backup) and TOLERANCE=(e.g. 1.0e-5)\n"
-                           "interactive mode if not enough arguments are passed.\n", p))
+                           "interactive mode if not enough arguments are passed.\n"
+                           "note: the HDF5 container layout follows the sources of the reference's FluSI tools (src/flusi); it could not be\n"
+                           "      compared with files written by them (they do not compile with current g++ and ship no sample files): the coded\n"
+                           "      bytes and coding attributes inside are bit-identical to the reference codec's, the container itself is unpinned.\n", p))
         return -1;
     int file_type = 0;
     double tol = 1e-16;
