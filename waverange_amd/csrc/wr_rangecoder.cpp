@@ -415,6 +415,7 @@ public:
         vb.active = 0;
         vb.gather = 0;
         vb.tab = &tabs_[0][0].lt;
+        vb.packed = &packed_[0][0];
         const uint8_t* ss[kCap];
         for (int k = 0; k < count_; k++) {
             EncGroup::Stream& s = st_[k];
@@ -456,6 +457,10 @@ public:
                     vb.low[k] = 0; vb.range[k] = 0; vb.sym[k] = nullptr; vb.out[k] = nullptr; vb.pos[k] = 0; vb.top[k] = 0xffffffffu;
                     for (int e = 0; e < kVecCand; e++) { vb.cand[e][k] = 0x100; vb.lt[e][k] = 0; vb.sy[e][k] = 0; }
                 }
+            if (vb.gather)
+                for (int k = 0; k < kCap; k++)
+                    if (vb.active >> k & 1)
+                        for (int b = 0; b < 256; b++) packed_[k][b] = tabs_[k][b].lt | (((uint32_t)b == tops_[k] ? 0u : tabs_[k][b].sy) << 16);
             vec_encode_block(&vb);
             for (int k = 0; k < count_; k++)
                 if (vb.active >> k & 1) { es_[k]->low = vb.low[k]; es_[k]->range = vb.range[k]; es_[k]->pos = vb.pos[k]; }
@@ -481,6 +486,7 @@ private:
     alignas(Enc) unsigned char store_[kCap][sizeof(Enc)];
     EncGroup::Stream st_[kCap];
     SymEntry tabs_[kCap][256];  // contiguous: the vector loop gathers {lt, sy} at (lane * 256 + symbol)
+    alignas(64) uint32_t packed_[kCap][256];  // the same as lt | sy << 16 (sy = 0: the largest symbol present) for the per-lane look-ups
     uint32_t tops_[kCap];
 };
 

@@ -13,7 +13,6 @@ namespace {
 
 constexpr uint32_t kTop = 0x80000000u;     // rangecod.c:121
 constexpr uint32_t kBottom = 0x00800000u;  // rangecod.c:129
-constexpr int kExtra = 7;                  // rangecod.c:128
 constexpr uint32_t kBlockSyms = 60000;     // defs.h:36
 
 // transpose of a 16 x 16 byte matrix held in 16 xmm registers (rows in, columns out)
@@ -276,7 +275,10 @@ void vec_decode_block_any(VecAnyBlock* b)
         if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
 }
 
-template <bool ALWAYS, bool GATHER>
+// MODE 0: {lt, sy} by comparing with the lane's candidates; 1: two 8-lane gathers from the lanes' tables; 2: a scalar load per
+// lane from the lanes' packed tables, returned to a vector by inserts (the symbols then come straight from the lanes'
+// streams, no transposes) -- AMD's gathers are microcoded: EPYC 9575F, 16 noise planes, one thread: see profiles/r03
+template <bool ALWAYS, int MODE>
 static void vec_encode_block_t(VecEncBlock* b)
 {
     const __mmask16 act = (__mmask16)b->active;
@@ -307,6 +309,7 @@ static void vec_encode_block_t(VecEncBlock* b)
     // Final bytes collect in the lane's 32-bit `pend` (count in `cnt`); when a lane holds four, all lanes store theirs
     // with one unaligned 4-byte store each (what lies beyond a lane's `cnt` is overwritten by its next store).
     const uint8_t* in[kVecLanes];
+    uint32_t step_of[kVecLanes];  // MODE 2: index mask, all ones for a lane with a stream, 0 for an idle one (it reads zeros[0] in every step)
     static const uint8_t zeros[16] = {0};
     alignas(64) uint8_t dummy[64];  // idle lanes store here (and never advance)
     alignas(64) uint64_t addr[kVecLanes];  // next write address of every lane
@@ -316,6 +319,9 @@ static void vec_encode_block_t(VecEncBlock* b)
         hbuf[j] = fbuf[j] = 0;
         addr[j] = (uint64_t)(uintptr_t)dummy;
         in[j] = zeros;
+        step_of[j] = on ? ~0u : 0u;
+        // an idle lane codes symbol 0 with {lt 0, sy 60000} for ever: its range stays where it is, above Bottom
+        if (MODE == 2 && !on) b->packed[j * 256] = kBlockSyms << 16;
         if (!on) continue;
         size_t p = b->pos[j] - 1;
         while (p > 0 && b->out[j][p] == 0xff) { fbuf[j]++; p--; }
@@ -364,15 +370,36 @@ static void vec_encode_block_t(VecEncBlock* b)
 
     for (uint32_t i = 0; i < kBlockSyms; i++) {
         // ---- symbols in: every 16 steps, 16 bytes of each plane, transposed to one row per step
-        if ((i & 15) == 0) {
-            for (int j = 0; j < kVecLanes; j++) rows[j] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in[j] + ((act >> j & 1) ? i : 0)));
-            transpose16x16(rows);
+        __m512i c = _mm512_setzero_si512();
+        if (MODE != 2) {
+            if ((i & 15) == 0) {
+                for (int j = 0; j < kVecLanes; j++) rows[j] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in[j] + ((act >> j & 1) ? i : 0)));
+                transpose16x16(rows);
+            }
+            c = _mm512_cvtepu8_epi32(rows[i & 15]);
         }
-        const __m512i c = _mm512_cvtepu8_epi32(rows[i & 15]);
-        // ---- {lt, sy} of the symbol: one of the lane's candidates, else the lane's table; or (GATHER: planes of any
-        // statistics) two 8-lane gathers of the {lt, sy} pairs from the lanes' tables
+        // ---- {lt, sy} of the symbol: one of the lane's candidates, else the lane's table; or (planes of any
+        // statistics) looked up per lane
         __m512i lt, sy;
-        if (GATHER) {
+        __mmask16 is_top_m = 0;
+        if (MODE == 2) {
+            __m128i x[4];
+#pragma GCC unroll 4
+            for (int g = 0; g < 4; g++) {
+                uint32_t e[4];
+#pragma GCC unroll 4
+                for (int k = 0; k < 4; k++) {
+                    const int j = 4 * g + k;
+                    e[k] = b->packed[j * 256 + in[j][i & step_of[j]]];
+                }
+                x[g] = _mm_insert_epi32(_mm_insert_epi32(_mm_insert_epi32(_mm_cvtsi32_si128((int)e[0]), (int)e[1], 1), (int)e[2], 2), (int)e[3], 3);
+            }
+            const __m512i ent = _mm512_inserti64x4(_mm512_castsi256_si512(_mm256_inserti128_si256(_mm256_castsi128_si256(x[0]), x[1], 1)),
+                                                   _mm256_inserti128_si256(_mm256_castsi128_si256(x[2]), x[3], 1), 1);
+            lt = _mm512_and_si512(ent, _mm512_set1_epi32(0xffff));
+            sy = _mm512_srli_epi32(ent, 16);
+            is_top_m = _mm512_cmpeq_epu32_mask(sy, _mm512_setzero_si512());
+        } else if (MODE == 1) {
             const __m512i idx = _mm512_add_epi32(c, lane_base);  // lane * 256 + symbol: index of the 8-byte {lt, sy} entry
             const __m512i p0 = _mm512_i32gather_epi64(_mm512_castsi512_si256(idx), b->tab, 8);
             const __m512i p1 = _mm512_i32gather_epi64(_mm512_extracti64x4_epi64(idx, 1), b->tab, 8);
@@ -429,7 +456,7 @@ static void vec_encode_block_t(VecEncBlock* b)
         const __m512i r = _mm512_or_si512(ev, od);
         const __m512i t = _mm512_mullo_epi32(r, lt);
         low = _mm512_add_epi32(low, t);
-        const __mmask16 is_top = _mm512_cmpeq_epu32_mask(c, top);
+        const __mmask16 is_top = MODE == 2 ? is_top_m : _mm512_cmpeq_epu32_mask(c, top);
         range = _mm512_mask_sub_epi32(_mm512_mullo_epi32(r, sy), is_top, range, t);
     }
     // ---- back to the form the scalar code keeps: everything written, the held byte and its 0xff bytes included
@@ -460,9 +487,10 @@ void vec_encode_block(VecEncBlock* b)
         for (int e = 0; e < kVecCand; e++) if (b->sy[e][j] > best) best = b->sy[e][j];
         if ((uint64_t)best * 100 < (uint64_t)kBlockSyms * 97) busy++;
     }
-    if (b->gather) vec_encode_block_t<true, true>(b);
-    else if (busy >= 2) vec_encode_block_t<true, false>(b);
-    else vec_encode_block_t<false, false>(b);
+    static const bool use_gathers = getenv("WR_VEC_ENC_GATHER") && atoi(getenv("WR_VEC_ENC_GATHER"));
+    if (b->gather) { if (use_gathers) vec_encode_block_t<true, 1>(b); else vec_encode_block_t<true, 2>(b); }
+    else if (busy >= 2) vec_encode_block_t<true, 0>(b);
+    else vec_encode_block_t<false, 0>(b);
 }
 
 }  // namespace wrrc

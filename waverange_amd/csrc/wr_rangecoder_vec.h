@@ -45,7 +45,9 @@ struct VecEncBlock {
     uint32_t cand[kVecCand][kVecLanes], lt[kVecCand][kVecLanes], sy[kVecCand][kVecLanes];  // unused entries: cand = 0x100
     const uint32_t* tab;             // [16 lanes][256 symbols]{lt, sy}: symbols outside the candidates
     uint32_t top[kVecLanes];         // largest symbol present: its interval is open-ended (rangecod.c:227)
-    int gather;                      // != 0: {lt, sy} of every symbol gathered from `tab` (lanes with any statistics); else candidates
+    int gather;                      // != 0: {lt, sy} of every symbol looked up per lane (lanes with any statistics); else candidates
+    uint32_t* packed;                // gather mode: [16 lanes][256 symbols] lt | sy << 16, sy = 0 marking the largest symbol present
+                                     // (filled by the caller for the active lanes; entry 0 of idle lanes is overwritten)
 };
 void vec_encode_block(VecEncBlock* b);
 
