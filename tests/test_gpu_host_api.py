@@ -345,14 +345,17 @@ def test_two_phase_decode(ctx, api, oracle):
     assert np.array_equal(out, g)
 
 
-@pytest.mark.parametrize("env", [{"WR_WINDOW_BLOCKS": "1"}, {"WR_WINDOW_BLOCKS": "2", "WR_NO_DMA": "1"}],
-                         ids=["one_block_windows", "two_block_windows_hipMemcpyAsync"])
+@pytest.mark.parametrize("env", [{"WR_WINDOW_BLOCKS": "1"}, {"WR_WINDOW_BLOCKS": "2", "WR_NO_DMA": "1"},
+                                 {"WR_WINDOW_BLOCKS": "4", "WR_PLANE_CHUNK_MB": "1"}],
+                         ids=["one_block_windows", "two_block_windows_hipMemcpyAsync", "planes_in_1MiB_chunks"])
 def test_small_windows_on_every_path(env):
     """The planes reach the host coder through 15 MB windows of a pinned ring; with WR_WINDOW_BLOCKS=1 a window is one
     coder block (60000 symbols), so the small fields of the tests in this file and of the parity file cross dozens of
     window boundaries on every path (thread per plane, grouped threads, the pool, two-call decodes, the drop-in
     symbols): run them again in a child process with that setting, and once more with the window copies on
-    hipMemcpyAsync and the copy streams (WR_NO_DMA=1: what happens without ROCr's DMA interface)."""
+    hipMemcpyAsync and the copy streams (WR_NO_DMA=1: what happens without ROCr's DMA interface), and once with the planes
+    in chunks of 1 MiB that drain under the encoder's coder (the storage of large planes, wr_pipeline.cpp: here every plane
+    of 2 MiB or more)."""
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("(codec or trivial or drop_in or local_cutoff or error_paths or concurrent_contexts or grouped_coder or random_shapes "
            "or zero_minimum or host_entry_points or plane_ordered or coder_pool or two_phase or beyond_the_launch "
@@ -497,3 +500,65 @@ def test_pool_stopped_under_running_calls(api, oracle):
         api.set_coder_pool(0)
     if errs:
         raise errs[0]
+
+
+CHUNK_WORKER = r'''
+import os, sys, threading
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+from oracle.loader import Oracle
+from waverange_amd import api, synth
+from util import bits_equal
+api.set_verbosity(0)
+o = Oracle()
+shape = (128, 160, 192)                      # 3.9 M elements: planes of 4 chunks of 1 MiB
+fields = [synth.field(shape[2], shape[1], shape[0], seed=70 + k) for k in range(3)]
+want = [o.encode(f, 1e-8) for f in fields]
+recs = [o.decode(w, f.shape) for w, f in zip(want, fields)]
+errs = []
+def caller(k):
+    try:
+        with api.Context(0) as c:
+            out = np.empty_like(fields[k])
+            for rep in range(4):
+                enc, _ = c.encode_host(fields[k], 1e-8)
+                assert enc["len_enc_vec"] == want[k]["len_enc_vec"] and np.array_equal(enc["data"], want[k]["data"]), "coded bytes"
+                enc["data"] = enc["data"].copy()
+                if rep %% 2:
+                    c.decode_begin(fields[k].shape, enc); c.decode_finish_host(out)
+                else:
+                    c.decode_host(out, enc)
+                assert bits_equal(out, recs[k]), "reconstruction"
+    except BaseException as exc:
+        errs.append(exc)
+if os.environ.get("POOL"):
+    api.set_coder_pool(4, 4)
+ths = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
+for t in ths: t.start()
+for t in ths: t.join()
+if errs: raise errs[0]
+chunk = 1 << 20
+print("plane bytes", api.stat(api.STAT_DEVICE_PLANE_BYTES), "chunks", api.stat(api.STAT_DEVICE_PLANE_BYTES) // chunk)
+'''
+
+
+@pytest.mark.parametrize("limit,pool", [(None, False), ("40", False), ("40", True), ("34", True)])
+def test_chunked_planes_drain_and_wait(tmp_path, limit, pool):
+    """Large planes live in chunks (the kernels index a table of them, wrk::PlaneRef); an encoder's chunks go back to the pool as
+    its coder has fetched the windows they hold, and a call that finds no device memory for a plane waits for chunks to come
+    back instead of failing (wr_pipeline.cpp: plane_prepare, plane_buffer_wait; WR_PLANE_LIMIT_MB caps the planes' memory).  Three callers at once, each field with 8 planes of 4 chunks (tol 1e-8): every coded byte and every
+    reconstruction equal the oracle's -- with no limit, with a pool of 40 chunks (less than the 3 x 8 x 4 x 2 that three
+    encodes and decodes would hold at once without draining and waiting), and with 34 (hardly more than the 32 of one
+    field's planes, which a decode holds all at once: the callers take turns)."""
+    script = tmp_path / "chunks.py"
+    script.write_text(CHUNK_WORKER % dict(root=ROOT))
+    env = dict(os.environ, WR_PLANE_CHUNK_MB="1", WR_WINDOW_BLOCKS="2")
+    if limit:
+        env["WR_PLANE_LIMIT_MB"] = limit
+    if pool:
+        env["POOL"] = "1"
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    chunks = int(r.stdout.split("chunks")[-1])
+    if limit:
+        assert chunks <= int(limit), r.stdout

@@ -168,7 +168,7 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         info->deps_vec[ilay] = s.deps;
         if (verbose()) { printf("min=%g max=%g\n", lo, hi); printf("ilay=%u deps=%g\n", ilay, s.deps); }
         const bool resid_upd = !s.last || c->keep_residual;
-        uint8_t* const d_plane = plane_buf(ilay);  // device memory of this plane (the error is set if there is none)
+        const wrk::PlaneRef* const d_plane = plane_buf(ilay);  // device memory of this plane (the error is set if there is none)
         if (!d_plane) return WR_ERR_HIP;
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
         if (local) {
@@ -179,10 +179,10 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
             lc.tol_scale = info->tolabs / tolrel;
             lc.tolabs = info->tolabs;
             lc.span = hi - lo;
-            wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_plane, lc,
+            wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_plane->chunk[0], lc,  // (one array: plane_prepare(contiguous))
                                       c->d_partial, c->h_result_dev, c->stream);
         } else
-        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_plane, resid_upd,
+        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, *d_plane, resid_upd,
                             c->d_partial, c->h_result_dev, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
         HIPCHK(hipGetLastError());
@@ -230,7 +230,9 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     Cutoff cut; cut.vec = &tolrel;
     double* resid = nullptr;
     const size_t pitch = wr_plane_pitch((size_t)nx * ny * nz);
-    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, [&](unsigned l) { return d_planes + l * pitch; }, info, nullptr,
+    wrk::PlaneRef refs[WR_NLAYMAX];
+    for (int l = 0; l < WR_NLAYMAX; l++) refs[l] = wrk::plane_ref(d_planes + l * pitch);
+    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, [&](unsigned l) { return &refs[l]; }, info, nullptr,
                                 [](unsigned) { return WR_OK; }, [](unsigned, bool) { return WR_OK; }, &resid);
     if (rc == WR_OK && resid != d_fld && info->nlay)  // d_fld holds the residual afterwards (header contract)
         if (hipMemcpyAsync(d_fld, resid, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
@@ -261,7 +263,7 @@ int wr_dev_decode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, const
     memset(&p, 0, sizeof p);
     p.nlay = info->nlay;
     for (int l = 0; l < p.nlay; l++) {
-        p.q[l] = d_planes + l * wr_plane_pitch(n);
+        p.q[l] = wrk::plane_ref(d_planes + l * wr_plane_pitch(n));
         p.deps[l] = info->deps_vec[l];
         p.minval[l] = info->minval_vec[l];
     }
@@ -359,10 +361,26 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         double* resid = d_fld;
         auto after_quant = [&](unsigned l) -> int {
             // block histograms of plane l on the kernel stream, behind the read-back of the next plane's min/max
-            wrk::block_histograms(c->ps[l].dev, n, slot->hist + l * hist_per_plane, c->stream);
+            wrk::block_histograms(c->ps[l].ref, n, slot->hist + l * hist_per_plane, c->stream);
             return WR_OK;
         };
-        auto plane_buf = [&](unsigned l) -> uint8_t* { return plane_prepare(c, (int)l, n, false) == WR_OK ? c->ps[l].dev : nullptr; };
+        // (a plane that has to wait for device memory gives the kernel stage up meanwhile: cu)
+        StageLock cu(pool->cu_mu, std::defer_lock);
+        // (the local-cutoff quantizer scatters into the plane by wavelet-space index: it wants one array)
+        const bool one_array = cut.count() > 1;
+        auto plane_buf = [&](unsigned l) -> const wrk::PlaneRef* { return plane_prepare(c, (int)l, n, false, one_array, &cu) == WR_OK ? &c->ps[l].ref : nullptr; };
+        // pool: plane k goes to the workers once its histograms are on the host (they set off when it completed)
+        unsigned handed = 0;  // planes that have a coder (a pool job or, if the pool refused, a thread of this call)
+        auto submit_plane = [&](unsigned k) {
+            if (handed >> k & 1) return;
+            if (xfer_wait(&c->x_plane[k]) != WR_OK) { copy_failed[k] = 1; return; }
+            handed |= 1u << k;
+            wrrc::PlaneJob& j = jobs[k];
+            j.kind = wrrc::PlaneJob::kEncode;
+            j.src = nullptr; j.io = &c->ps[k].io; j.dst = c->enc_buf[k]; j.n = n; j.hist = c->h_hist + k * hist_per_plane;
+            if (wrrc::pool_submit(&j, 1, &batch)) pool_mask |= 1u << k;
+            else workers.v.emplace_back(code_group, k, k + 1);  // the pool was stopped meanwhile: a thread of this call codes the plane
+        };
         auto plane_ready = [&](unsigned l, bool) -> int {
             // plane l and its histograms are complete on the device: the histograms go to pinned host memory, the
             // plane's first chunk sets off into its ring, and a coder thread waits for them
@@ -372,11 +390,15 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             plane_prefetch(c, (int)l);
             planes_started = l + 1;
             if (per_plane) workers.v.emplace_back(code_group, l, l + 1);
+            // the plane before this one is handed to the pool now (its histograms have had a quantizer launch's time to
+            // arrive): its coder drains it while the stage goes on -- what a later plane of this call may be waiting for
+            // if device memory is short (plane_prepare)
+            if (pooled && l > 0) submit_plane(l - 1);
             return WR_OK;
         };
         {
             // ---- stage "kernels"
-            StageLock cu(pool->cu_mu);
+            cu.lock();
             rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, info, &local, after_quant, plane_ready, &resid);
             (void)hipStreamSynchronize(c->stream);
             if (rc == WR_OK && c->keep_residual && info->nlay && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
@@ -384,6 +406,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
                     hipStreamSynchronize(c->stream) != hipSuccess)
                     rc = fail(WR_ERR_HIP, "residual copy failed");
             }
+            cu.unlock();
         }
         // ---- stage "down": the histograms were sent off as the planes completed; the residual follows them
         if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
@@ -395,13 +418,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         // is handed over the moment its histograms are on the host.
         for (unsigned l = 0; l < planes_started; l++) {
             if (xfer_wait(&c->x_plane[l]) != WR_OK) copy_failed[l] = 1;
-            if (pooled && rc == WR_OK && !copy_failed[l]) {
-                wrrc::PlaneJob& j = jobs[l];
-                j.kind = wrrc::PlaneJob::kEncode;
-                j.src = nullptr; j.io = &c->ps[l].io; j.dst = c->enc_buf[l]; j.n = n; j.hist = c->h_hist + l * hist_per_plane;
-                if (wrrc::pool_submit(&j, 1, &batch)) pool_mask |= 1u << l;
-                else workers.v.emplace_back(code_group, l, l + 1);  // the pool was stopped meanwhile: a thread of this call codes the plane
-            }
+            if (pooled && rc == WR_OK && !copy_failed[l]) submit_plane(l);
         }
         t_gpu_done = now();
         // the slot goes back here: the planes are in device buffers of their own
@@ -515,6 +532,9 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
 
     if (host_half) {
         c->pend_valid = false;  // whatever an earlier begin parked here is overwritten now
+        // one decode at a time gathers its planes: a decoder keeps them all until its field is done, so two that each hold
+        // half of theirs and wait for the other half would never finish
+        std::lock_guard<std::mutex> gather(pool->planes.gather_mu);
         for (int l = 0; l < nlay; l++) if (int rc = plane_prepare(c, l, n, true)) return rc;
     }
     for (int l = 0; l < nlay; l++)
@@ -600,7 +620,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         wrk::DequantParams p;
         memset(&p, 0, sizeof p);
         p.nlay = nlay;
-        for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = c->ps[l].dev; }
+        for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = c->ps[l].ref; }
         double* d_fld = fld.host ? slot->field : fld.dev;
         {
             // ---- stage "kernels"

@@ -118,9 +118,13 @@ struct DevPlanes {
     }
     void give(const Buf& b)
     {
-        std::lock_guard<std::mutex> lk(mu);
-        idle.push_back(b);
+        { std::lock_guard<std::mutex> lk(mu); idle.push_back(b); }
+        cv.notify_all();
     }
+    std::condition_variable cv;   // a buffer came back (calls waiting for device memory: plane_prepare)
+    std::mutex gather_mu;         // held by the one decode that is gathering its planes (wr_codec.cpp)
+    size_t chunk_bytes = 0;       // large planes live in chunks of this size or more (WR_PLANE_CHUNK_MB, default 32 MiB; 0: not read yet)
+    size_t chunk_limit = 0;       // WR_PLANE_LIMIT_MB: device memory the planes of all calls may take together (0: what the device gives)
 };
 
 struct DevPool {
@@ -165,7 +169,17 @@ struct wr_ctx {
     // chunks through which the host coder reads (encode) or writes (decode) it, window by window (wrrc::PlaneWindow)
     struct PlaneStream {
         wr_ctx* c = nullptr;
-        uint8_t* dev = nullptr; size_t dev_bytes = 0;
+        // Where the plane is: one buffer, or -- a large plane -- chunks of 2^ref.shift bytes each that are borrowed together
+        // and, on the encoder's side, go back one by one as the host coder has fetched the windows they hold: a plane is
+        // complete the moment the quantizer has run and then drains for seconds, so on average half of it is gone and a third
+        // more fields in flight fit into the same HBM.  (Chunks as plain buffers with a table the kernels index,
+        // wrk::PlaneRef: backing one address range with chunks that come and go -- hipMemMap / hipMemUnmap -- leaves kernels
+        // reading the chunks that were there before, profiles/r03/t_vmm_probe.txt.)
+        uint8_t* dev = nullptr; size_t dev_bytes = 0;   // dev: the first byte's address (non-null = the plane has storage)
+        wrk::PlaneRef ref;
+        std::vector<DevPlanes::Buf> chunks;             // chunked form: chunk k, p = nullptr once it went back
+        size_t released_chunks = 0;
+        bool drain = false;                             // hand chunks back as the windows behind them have been fetched
         size_t n = 0;
         uint8_t* buf[2] = {nullptr, nullptr};  // pinned (pageable if the host has no pinned memory left), allocated at first use, kept
         bool buf_pinned[2] = {false, false};
@@ -290,7 +304,9 @@ int xfer_wait(wr_ctx::Xfer* x);
 
 using PlaneStream = wr_ctx::PlaneStream;
 void plane_release(wr_ctx* c, int l);
-int plane_prepare(wr_ctx* c, int l, size_t n, bool decode);
+// contiguous: the plane must be one array (the local-cutoff quantizer).  unlock_while_waiting: a stage lock the caller holds
+// and that must not be held while waiting for device memory that other calls' kernel stages have to free (nullptr: none)
+int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous = false, std::unique_lock<std::mutex>* unlock_while_waiting = nullptr);
 void plane_prefetch(wr_ctx* c, int l);
 std::string plane_log(wr_ctx* c, int l, size_t n, const wr_enc_info* info, bool encode, size_t len);
 

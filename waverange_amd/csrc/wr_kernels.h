@@ -25,11 +25,29 @@ void minmax(const double* x, size_t n, double* partial, double* result, hipStrea
 // equal values): out[0] = index+1 of that element (0 if none).  Rare path (min == 0 only).
 void last_zero_index(const double* x, size_t n, unsigned long long* out, hipStream_t st);
 
+// A quantized plane as the kernels see it: one array, or up to kPlaneChunks chunks of 2^shift bytes each (a large plane
+// of a call in flight lives in chunks that come and go as the host coder drains or fills it: wr_pipeline.cpp).  Byte i of
+// the plane is chunk[i >> shift][i & (2^shift - 1)]; a chunk is a multiple of 4096 bytes, so the 4096-element groups the
+// kernels work in, and their 16-byte loads, never straddle two chunks.
+constexpr int kPlaneChunks = 16;
+struct PlaneRef {
+    uint8_t* chunk[kPlaneChunks];
+    unsigned shift;
+    __host__ __device__ uint8_t* at(size_t i) const { return chunk[i >> shift] + (i & (((size_t)1 << shift) - 1)); }
+};
+inline PlaneRef plane_ref(const uint8_t* base)  // a plane that is one array
+{
+    PlaneRef r;
+    for (int k = 0; k < kPlaneChunks; k++) r.chunk[k] = const_cast<uint8_t*>(base);
+    r.shift = 63;
+    return r;
+}
+
 // ---- quantizer plane (wrappers.cpp:339-340, 384-398) fused with the min/max of the residual
 // q[j] = (uchar)(aopt*x[j] + bopt); if write_resid: x[j] -= q[j]*deps + minval and
 // result[0..1] = min/max of the new residual.
 void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval,
-                    uint8_t* q, bool write_resid, double* partial, double* result, hipStream_t st);
+                    const PlaneRef& q, bool write_resid, double* partial, double* result, hipStream_t st);
 
 // ---- quantizer plane with the non-uniform (local) cutoff mask (wrappers.cpp:343-379, 397-398):
 // loops over PHYSICAL positions, maps each to its wavelet-space index (ind_p2w_3d,
@@ -47,7 +65,7 @@ void quantize_plane_local(double* x, size_t n, double aopt, double bopt, double 
 
 // ---- decoder accumulation (wrappers.cpp:480, 513-514): acc = 0; acc += q_l*deps_l + min_l, l in order
 struct DequantParams {
-    const uint8_t* q[8];
+    PlaneRef q[8];
     double deps[8];
     double minval[8];
     int nlay;
@@ -63,7 +81,7 @@ void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, i
                  hipStream_t st);
 // per-60000-symbol-block byte histograms of a plane (feeds the host range coder's model):
 // hist[b*256 + v] = count of value v in block b (uint16, block size < 65536)
-void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st);
+void block_histograms(const PlaneRef& q, size_t n, uint16_t* hist, hipStream_t st);
 // bytes (a multiple of 16, 16-byte aligned pointers) copied by `workgroups` workgroups; src / dst may be pinned host memory
 void copy_kernel(void* dst, const void* src, size_t bytes, int workgroups, hipStream_t st);
 

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant(double* __restrict__ x
 constexpr int Q_CHUNK = 4096;
 template <bool RESID>
 __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_lds(double* __restrict__ x, size_t nchunks, double aopt, double bopt,
-                                                              double deps, double minval, uint8_t* __restrict__ q,
+                                                              double deps, double minval, PlaneRef q,
                                                               double* __restrict__ partial)
 {
     __shared__ uchar2 sq[Q_CHUNK / 2];
@@ -471,19 +471,20 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_lds(double* __restrict
             }
         }
         __syncthreads();
-        reinterpret_cast<uint4*>(q + ch * Q_CHUNK)[t] = reinterpret_cast<const uint4*>(sq)[t];
+        reinterpret_cast<uint4*>(q.at(ch * Q_CHUNK))[t] = reinterpret_cast<const uint4*>(sq)[t];
         __syncthreads();
     }
     if (RESID) block_minmax(lo, hi, partial);
 }
 
 // merges the partials of the chunked kernel (first g1) and of the tail kernel (g2 more)
-void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval, uint8_t* q,
+void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval, const PlaneRef& q,
                     bool write_resid, double* partial, double* result, hipStream_t st)
 {
     static const bool lds_ok = !(getenv("WR_QUANT_DIRECT") && atoi(getenv("WR_QUANT_DIRECT")));
-    const bool aligned = (((uintptr_t)x | (uintptr_t)q) & 15) == 0;
-    const size_t nchunks = (lds_ok && aligned) ? n / Q_CHUNK : 0;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)q.chunk[0]) & 15) == 0;
+    const bool chunked = q.shift < 63;  // (chunks are device allocations: aligned; the direct form below wants one array)
+    const size_t nchunks = ((lds_ok || chunked) && aligned) ? n / Q_CHUNK : 0;
     int g1 = 0;
     if (nchunks) {
         g1 = (int)(nchunks < (size_t)WR_RED_BLOCKS / 2 ? nchunks : (size_t)WR_RED_BLOCKS / 2);
@@ -495,8 +496,10 @@ void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, 
     if (done < n) {  // remainder (or everything, for unaligned pointers): direct form
         g2 = red_grid(n - done, 2);
         if (g2 > WR_RED_BLOCKS / 2) g2 = WR_RED_BLOCKS / 2;
-        if (write_resid) hipLaunchKernelGGL(k_quant<true>, dim3(g2), dim3(WR_RED_THREADS), 0, st, x + done, n - done, aopt, bopt, deps, minval, q + done, partial + 2 * g1);
-        else hipLaunchKernelGGL(k_quant<false>, dim3(g2), dim3(WR_RED_THREADS), 0, st, x + done, n - done, aopt, bopt, deps, minval, q + done, partial + 2 * g1);
+        // (a chunked plane: the remainder is shorter than a group of 4096 and lies in one chunk)
+        uint8_t* const qd = q.at(done);
+        if (write_resid) hipLaunchKernelGGL(k_quant<true>, dim3(g2), dim3(WR_RED_THREADS), 0, st, x + done, n - done, aopt, bopt, deps, minval, qd, partial + 2 * g1);
+        else hipLaunchKernelGGL(k_quant<false>, dim3(g2), dim3(WR_RED_THREADS), 0, st, x + done, n - done, aopt, bopt, deps, minval, qd, partial + 2 * g1);
     }
     if (write_resid) hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g1 + g2, result);
 }
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_dequant(double* __restrict__
 #pragma unroll
         for (int l = 0; l < 8; l++) {
             if (l < p.nlay) {
-                uchar2 qq = reinterpret_cast<const uchar2*>(p.q[l])[i];
+                uchar2 qq = reinterpret_cast<const uchar2*>(p.q[l].chunk[0])[i];  // (this form works on plain arrays: dequant_accum)
                 a.x = a.x + ((double)qq.x * p.deps[l] + p.minval[l]);
                 a.y = a.y + ((double)qq.y * p.deps[l] + p.minval[l]);
             }
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_dequant(double* __restrict__
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double a = 0.0;
-        for (int l = 0; l < p.nlay; l++) a = a + ((double)p.q[l][n - 1] * p.deps[l] + p.minval[l]);
+        for (int l = 0; l < p.nlay; l++) a = a + ((double)p.q[l].chunk[0][n - 1] * p.deps[l] + p.minval[l]);
         acc[n - 1] = a;
     }
 }
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, s
         const size_t base = ch * DQ_CHUNK;
 #pragma unroll
         for (int l = 0; l < 8; l++)
-            if (l < p.nlay) sq[l][t] = reinterpret_cast<const uint4*>(p.q[l] + base)[t];
+            if (l < p.nlay) sq[l][t] = reinterpret_cast<const uint4*>(p.q[l].at(base))[t];
         __syncthreads();
         double2* a2 = reinterpret_cast<double2*>(acc + base);
 #pragma unroll
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, s
 void dequant_accum(double* acc, size_t n, const DequantParams& p, hipStream_t st)
 {
     bool aligned = ((uintptr_t)acc & 15) == 0;
-    for (int l = 0; l < p.nlay; l++) aligned = aligned && ((uintptr_t)p.q[l] & 15) == 0;
+    for (int l = 0; l < p.nlay; l++) aligned = aligned && ((uintptr_t)p.q[l].chunk[0] & 15) == 0;
     const size_t nchunks = aligned ? n / DQ_CHUNK : 0;
     if (nchunks) {
         const size_t g = nchunks < 256 * 8 ? nchunks : 256 * 8;
@@ -619,8 +622,8 @@ void dequant_accum(double* acc, size_t n, const DequantParams& p, hipStream_t st
     }
     const size_t done = nchunks * DQ_CHUNK;
     if (done < n) {  // remainder (or everything, for unaligned plane pointers): direct form
-        DequantParams r = p;
-        for (int l = 0; l < p.nlay; l++) r.q[l] = p.q[l] + done;
+        DequantParams r = p;  // the remainder of every plane as a plain array (a chunked plane: shorter than a group, in one chunk)
+        for (int l = 0; l < p.nlay; l++) r.q[l] = plane_ref(p.q[l].at(done));
         hipLaunchKernelGGL(k_dequant, dim3(red_grid(n - done, 2)), dim3(WR_RED_THREADS), 0, st, acc + done, n - done, r);
     }
 }
@@ -697,7 +700,7 @@ void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, i
 // field are dominated by one value, so (a) a lane reads 16 symbols at once and adds a run of equal
 // ones with a single atomic, and (b) the lanes spread over 8 copies of the histogram, which bounds the
 // same-address serialisation of the LDS atomics.  (60000 = 16 * 3750; the plane base is 256-B aligned.)
-__global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, size_t n, uint16_t* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_hist(PlaneRef q, size_t n, uint16_t* __restrict__ hist)
 {
     constexpr int COPIES = 8;
     __shared__ unsigned int h[COPIES][256 + 1];  // +1: the copies start in different banks
@@ -707,9 +710,14 @@ __global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, siz
     const size_t b1 = (b0 + 60000 < n) ? b0 + 60000 : n;
     unsigned int* mine = h[threadIdx.x & (COPIES - 1)];
     const size_t nvec = (b1 - b0) / 16;
-    const uint4* qv = reinterpret_cast<const uint4*>(q + b0);
+    // a block of 60000 symbols may straddle two chunks of the plane (never more: a chunk is megabytes); 60000 b and the
+    // chunk size are multiples of 16, so a 16-byte load lies in one of them
+    const size_t c0 = (b0 < n ? b0 : (n ? n - 1 : 0)) >> q.shift, edge = (c0 + 1) << q.shift;  // (the empty final block reads nothing)
+    const uint8_t* const p0 = q.chunk[c0] + (b0 - (c0 << q.shift));
+    const uint8_t* const p1 = edge < b1 ? q.chunk[c0 + 1] : p0;
+    auto sym_ptr = [&](size_t i) -> const uint8_t* { return i < edge ? p0 + (i - b0) : p1 + (i - edge); };
     for (size_t v = threadIdx.x; v < nvec; v += 256) {
-        const uint4 w = qv[v];
+        const uint4 w = *reinterpret_cast<const uint4*>(sym_ptr(b0 + 16 * v));
         const unsigned int words[4] = {w.x, w.y, w.z, w.w};
         unsigned int prev = words[0] & 0xff, run = 0;
 #pragma unroll
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint8_t* __restrict__ q, siz
         }
         atomicAdd(&mine[prev], run);
     }
-    for (size_t i = b0 + nvec * 16 + threadIdx.x; i < b1; i += 256) atomicAdd(&mine[q[i]], 1u);
+    for (size_t i = b0 + nvec * 16 + threadIdx.x; i < b1; i += 256) atomicAdd(&mine[*sym_ptr(i)], 1u);
     __syncthreads();
     unsigned int tot = 0;
     for (int c = 0; c < COPIES; c++) tot += h[c][threadIdx.x];
@@ -745,7 +753,7 @@ void copy_kernel(void* dst, const void* src, size_t bytes, int workgroups, hipSt
     hipLaunchKernelGGL(k_copy16, dim3(workgroups), dim3(256), 0, st, static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16);
 }
 
-void block_histograms(const uint8_t* q, size_t n, uint16_t* hist, hipStream_t st)
+void block_histograms(const PlaneRef& q, size_t n, uint16_t* hist, hipStream_t st)
 {
     const int nb = (int)(n / 60000 + 1);  // includes the (possibly empty) final block
     hipLaunchKernelGGL(k_hist, dim3(nb), dim3(256), 0, st, q, n, hist);

@@ -181,10 +181,75 @@ void plane_release(wr_ctx* c, int l)
 {
     PlaneStream& s = c->ps[l];
     if (!s.dev) return;
-    DevPlanes::Buf b; b.p = s.dev; b.bytes = s.dev_bytes;
-    c->pool->planes.give(b);
+    if (!s.chunks.empty()) {
+        for (DevPlanes::Buf& b : s.chunks)
+            if (b.p) { c->pool->planes.give(b); b.p = nullptr; }
+        s.chunks.clear();
+    } else {
+        DevPlanes::Buf b; b.p = s.dev; b.bytes = s.dev_bytes;
+        c->pool->planes.give(b);
+    }
     s.dev = nullptr; s.dev_bytes = 0;
+    s.released_chunks = 0; s.drain = false;
 }
+
+namespace {
+
+// `count` bytes of the plane from byte `first` on, against the host buffer `host`: one piece, or two where the range
+// straddles a chunk boundary (a window is shorter than a chunk).  to_host: device -> host.
+int plane_pieces(const PlaneStream& s, size_t first, size_t count, uint8_t* host, bool to_host, Piece out[4])
+{
+    int k = 0;
+    while (count && k < 4) {
+        const size_t room = s.chunks.empty() ? count : (((first >> s.ref.shift) + 1) << s.ref.shift) - first;
+        const size_t len = count < room ? count : room;
+        uint8_t* const dev = s.ref.at(first);
+        out[k++] = to_host ? Piece{host, dev, len} : Piece{dev, host, len};
+        first += len; host += len; count -= len;
+    }
+    return k;
+}
+
+void planes_configure(DevPlanes& dp)
+{
+    std::lock_guard<std::mutex> lk(dp.mu);
+    if (dp.chunk_bytes) return;
+    size_t mb = 32;
+    if (const char* e = getenv("WR_PLANE_CHUNK_MB")) { const long v = atol(e); if (v >= 1 && v <= 65536) mb = (size_t)v; }
+    size_t c = 1;
+    while (c < (mb << 20)) c <<= 1;   // a power of two: the kernels find a byte's chunk by a shift
+    dp.chunk_bytes = c;
+    if (const char* e = getenv("WR_PLANE_CHUNKS")) if (!atoi(e)) dp.chunk_bytes = ~(size_t)0 >> 1;  // WR_PLANE_CHUNKS=0: every plane one buffer
+    if (const char* e = getenv("WR_PLANE_LIMIT_MB")) { const long v = atol(e); if (v >= 1) dp.chunk_limit = (size_t)v << 20; }
+}
+
+// A plane buffer of `bytes`; if the device (or WR_PLANE_LIMIT_MB) has no room, waits for one to come back -- other calls'
+// encoders return their chunks as their coders advance, decoders when their field is done -- without the caller's kernel-stage
+// lock, which those other calls may need to get there.
+DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::mutex>* unlock_while_waiting, bool* unlocked)
+{
+    DevPlanes& dp = c->pool->planes;
+    const double t0 = now();
+    for (;;) {
+        if (!dp.chunk_limit || g_stat[WR_STAT_DEVICE_PLANE_BYTES].load() + bytes <= dp.chunk_limit || [&] {
+                std::lock_guard<std::mutex> lk(dp.mu);
+                for (const DevPlanes::Buf& b : dp.idle) if (b.bytes >= bytes && b.bytes / 2 <= bytes) return true;
+                return false; }()) {
+            const DevPlanes::Buf b = dp.take(bytes);
+            if (b.p) return b;
+        }
+        if (unlock_while_waiting && !*unlocked) {
+            (void)hipStreamSynchronize(c->stream);  // what this call has queued must not straddle the gap in its kernel stage
+            unlock_while_waiting->unlock();
+            *unlocked = true;
+        }
+        std::unique_lock<std::mutex> lk(dp.mu);
+        dp.cv.wait_for(lk, std::chrono::milliseconds(100));
+        if (now() - t0 > 300.0) return DevPlanes::Buf();
+    }
+}
+
+}  // namespace
 
 // Encoder side: the symbols [first, first + count) of the plane, fetched into the ring; the following chunk is
 // started into the buffer the coder has just left, so that it arrives while this one is being coded.
@@ -195,19 +260,28 @@ uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
     (void)hipSetDevice(c->device);  // coder threads: the pageable-copy fallback of xfer_start needs the device bound
     const size_t want = *count < kChunkSyms ? *count : kChunkSyms;
     const int b = s.cur ^ 1;
+    Piece pc[4];
     if (!(s.ahead && s.ahead_first == first)) {
         if (s.ahead) (void)xfer_wait(&s.x[b]);
-        const Piece pc = {s.buf[b], s.dev + first, want};
-        if (xfer_start(c, &s.x[b], &pc, 1, kDown) != WR_OK) s.err = 1;
+        const int np = plane_pieces(s, first, want, s.buf[b], true, pc);
+        if (xfer_start(c, &s.x[b], pc, np, kDown) != WR_OK) s.err = 1;
     }
     if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;
     s.copy_ms += s.x[b].ms;
     s.cur = b;
     s.ahead = false;
+    if (s.drain) {
+        // everything below `first` is coded, the window from `first` on is on the host: the chunks that lie wholly below `first`
+        // go back to the pool (the copy that is started next reads from first + want on)
+        const size_t upto = first >> s.ref.shift;
+        for (size_t k = s.released_chunks; k < upto && k < s.chunks.size(); k++)
+            if (s.chunks[k].p) { c->pool->planes.give(s.chunks[k]); s.chunks[k].p = nullptr; s.ref.chunk[k] = nullptr; }
+        if (upto > s.released_chunks) s.released_chunks = upto;
+    }
     const size_t next = first + want;
     if (next < s.n) {
-        const Piece pc = {s.buf[b ^ 1], s.dev + next, s.n - next < kChunkSyms ? s.n - next : kChunkSyms};
-        if (xfer_start(c, &s.x[b ^ 1], &pc, 1, kDown) == WR_OK) { s.ahead = true; s.ahead_first = next; }
+        const int np = plane_pieces(s, next, s.n - next < kChunkSyms ? s.n - next : kChunkSyms, s.buf[b ^ 1], true, pc);
+        if (xfer_start(c, &s.x[b ^ 1], pc, np, kDown) == WR_OK) { s.ahead = true; s.ahead_first = next; }
         else s.err = 1;
     }
     *count = want;
@@ -222,8 +296,9 @@ uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
     wr_ctx* const c = s.c;
     (void)hipSetDevice(c->device);
     if (s.win_count) {
-        const Piece pc = {s.dev + s.win_first, s.buf[s.cur], s.win_count};
-        if (xfer_start(c, &s.x[s.cur], &pc, 1, kUp) != WR_OK) s.err = 1;
+        Piece pc[4];
+        const int np = plane_pieces(s, s.win_first, s.win_count, s.buf[s.cur], false, pc);
+        if (xfer_start(c, &s.x[s.cur], pc, np, kUp) != WR_OK) s.err = 1;
         s.win_count = 0;
     }
     if (*count == 0) {
@@ -242,16 +317,51 @@ uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
 
 // plane l of n symbols for this call: a device buffer (kept if the context holds one that fits: a finish after a
 // begin), the ring, and the window callbacks of the direction
-int plane_prepare(wr_ctx* c, int l, size_t n, bool decode)
+int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous, std::unique_lock<std::mutex>* unlock_while_waiting)
 {
     PlaneStream& s = c->ps[l];
     const size_t bytes = wr_plane_pitch(n);
-    if (!s.dev || s.dev_bytes < bytes) {
+    DevPlanes& dp = c->pool->planes;
+    planes_configure(dp);
+    // a plane of two chunks or more lives in chunks: of the configured size, or larger so that kPlaneChunks of them hold it
+    size_t cb = dp.chunk_bytes;
+    while (cb < bytes && cb * wrk::kPlaneChunks < bytes) cb <<= 1;
+    const bool want_chunks = !contiguous && bytes >= 2 * cb && cb >= kChunkSyms;  // (a window never spans more than two chunks)
+    const bool have_chunks = !s.chunks.empty();
+    const bool reusable = s.dev && s.dev_bytes >= bytes && have_chunks == want_chunks && !s.released_chunks;
+    if (!reusable) {
         plane_release(c, l);
-        const DevPlanes::Buf b = c->pool->planes.take(bytes);
-        if (!b.p) return fail(WR_ERR_HIP, "out of device memory for a quantized plane (fewer calls in flight need less)");
-        s.dev = b.p; s.dev_bytes = b.bytes;
+        bool unlocked = false;
+        const char* const no_room = "out of device memory for a quantized plane: nothing came back in five minutes (fewer calls in flight need less)";
+        if (want_chunks) {
+            const size_t nch = (bytes + cb - 1) / cb;
+            unsigned shift = 0;
+            while (((size_t)1 << shift) < cb) shift++;
+            s.ref.shift = shift;
+            for (int k = 0; k < wrk::kPlaneChunks; k++) s.ref.chunk[k] = nullptr;
+            s.chunks.assign(nch, DevPlanes::Buf());
+            for (size_t k = 0; k < nch; k++) {
+                const DevPlanes::Buf b = plane_buffer_wait(c, cb, unlock_while_waiting, &unlocked);
+                if (!b.p) {
+                    for (DevPlanes::Buf& q : s.chunks) if (q.p) dp.give(q);
+                    s.chunks.clear();
+                    if (unlocked) unlock_while_waiting->lock();
+                    return fail(WR_ERR_HIP, no_room);
+                }
+                s.chunks[k] = b; s.ref.chunk[k] = b.p;
+            }
+            s.dev = s.chunks[0].p; s.dev_bytes = nch * cb;
+        } else {
+            const DevPlanes::Buf b = plane_buffer_wait(c, bytes, unlock_while_waiting, &unlocked);
+            if (!b.p) { if (unlocked) unlock_while_waiting->lock(); return fail(WR_ERR_HIP, no_room); }
+            s.dev = b.p; s.dev_bytes = b.bytes;
+            s.ref = wrk::plane_ref(b.p);
+        }
+        if (unlocked) unlock_while_waiting->lock();
     }
+    // an encoder's plane drains: its chunks go back as the coder has fetched the windows they hold -- unless the plane is
+    // looked at again afterwards (the verbose mode's per-plane diagnostics, plane_log)
+    s.drain = !s.chunks.empty() && !decode && !verbose();
     for (int b = 0; b < 2; b++) {
         if (s.buf[b]) continue;
         if (hipHostMalloc(reinterpret_cast<void**>(&s.buf[b]), kChunkBytes, hipHostMallocDefault) == hipSuccess) { s.buf_pinned[b] = true; continue; }
@@ -274,8 +384,9 @@ void plane_prefetch(wr_ctx* c, int l)
 {
     PlaneStream& s = c->ps[l];
     if (!s.n) return;
-    const Piece pc = {s.buf[s.cur ^ 1], s.dev, s.n < kChunkSyms ? s.n : kChunkSyms};
-    if (xfer_start(c, &s.x[s.cur ^ 1], &pc, 1, kDown) == WR_OK) { s.ahead = true; s.ahead_first = 0; }
+    Piece pc[4];
+    const int np = plane_pieces(s, 0, s.n < kChunkSyms ? s.n : kChunkSyms, s.buf[s.cur ^ 1], true, pc);
+    if (xfer_start(c, &s.x[s.cur ^ 1], pc, np, kDown) == WR_OK) { s.ahead = true; s.ahead_first = 0; }
     else s.err = 1;
 }
 
@@ -283,7 +394,15 @@ void plane_prefetch(wr_ctx* c, int l)
 std::string plane_log(wr_ctx* c, int l, size_t n, const wr_enc_info* info, bool encode, size_t len)
 {
     std::vector<uint8_t> q(n);
-    if (hipMemcpy(q.data(), c->ps[l].dev, n, hipMemcpyDeviceToHost) != hipSuccess) return std::string();
+    {
+        const PlaneStream& s = c->ps[l];
+        for (size_t at = 0; at < n;) {  // chunk by chunk (the verbose mode keeps an encoder's plane whole: plane_prepare)
+            const size_t room = s.chunks.empty() ? n - at : (((at >> s.ref.shift) + 1) << s.ref.shift) - at;
+            const size_t len = n - at < room ? n - at : room;
+            if (hipMemcpy(q.data() + at, s.ref.at(at), len, hipMemcpyDeviceToHost) != hipSuccess) return std::string();
+            at += len;
+        }
+    }
     unsigned lo = q[0], hi = q[0];
     for (size_t j = 1; j < n; j++) { unsigned v = q[j]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
     char b[256];
@@ -664,7 +783,7 @@ int wr_dev_quantize_plane(wr_ctx* c, double* d_x, size_t n, double deps, double 
     if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 1)) return fail(WR_ERR_ARG, "misaligned device pointer");
     const double aopt = 1.0 / deps;
     const double bopt = -minval * aopt + 0.5;
-    wrk::quantize_plane(d_x, n, aopt, bopt, deps, minval, d_q, true, c->d_partial, c->h_result_dev, c->stream);
+    wrk::quantize_plane(d_x, n, aopt, bopt, deps, minval, wrk::plane_ref(d_q), true, c->d_partial, c->h_result_dev, c->stream);
     HIPCHK(hipGetLastError());
     return read_minmax(c, d_x, n, true, next_min, next_max);
 }
@@ -677,7 +796,7 @@ int wr_dev_dequant_accum(wr_ctx* c, double* d_acc, size_t n, int nlay, const uns
     wrk::DequantParams p;
     memset(&p, 0, sizeof p);
     p.nlay = nlay;
-    for (int l = 0; l < nlay; l++) { p.q[l] = d_planes[l]; p.deps[l] = deps[l]; p.minval[l] = minval[l]; }
+    for (int l = 0; l < nlay; l++) { p.q[l] = wrk::plane_ref(d_planes[l]); p.deps[l] = deps[l]; p.minval[l] = minval[l]; }
     wrk::dequant_accum(d_acc, n, p, c->stream);
     HIPCHK(hipGetLastError());
     return WR_OK;
