@@ -160,7 +160,7 @@ def take_cpu_share(local_rank, gpus_on_node):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=1.5):
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=2.0):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -203,11 +203,13 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # field and the pool of output fields (two-phase decode) are a fixed 1 + out_pool field sizes in host-to-host mode.
     # HBM per field in flight: the planes of its encoder and decoder contexts (up to 4 + 4 at the bench's tolerances =
     # one field size) next to three work-space slots of 2.2 field sizes; resident mode: two field buffers per lane more
-    per_lane = 0.75 * field_bytes
+    per_lane = 0.6 * field_bytes
     fixed = (1 + out_pool) * field_bytes if host_mode else 0
     by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
     # (planes_per_field: 1 byte per element and plane, encoder and decoder context of a lane each hold a field's planes)
-    by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
+    # an encoder's planes drain as its coder advances (half of them are gone on average), a decoder's stay until its field is
+    # done: 0.75 of the two contexts' worst case; a call that finds no room for a plane waits for chunks to come back
+    by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((0.75 * planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / mem_share / 2 ** 30, 1) if mem else None,
                   "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
@@ -330,8 +332,8 @@ def main():
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=12, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
-    ap.add_argument("--fields-per-cpu", type=float, default=1.5, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
+    ap.add_argument("--jobs", type=int, default=16, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
+    ap.add_argument("--fields-per-cpu", type=float, default=2.0, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
