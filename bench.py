@@ -206,13 +206,20 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     per_lane = 0.6 * field_bytes
     fixed = (1 + out_pool) * field_bytes if host_mode else 0
     by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
+    # if host memory is what holds the lanes back, consumed coded streams hand their pages back to the system (drop_pages):
+    # ~0.25 field sizes per lane instead of 0.6, at ~3 % of the rate (the pages are faulted in and zeroed again for every field)
+    trim = False
+    if mem and by_mem < min(want, int(fields_per_cpu * cpus // ntols) if pooled else want):
+        trim = True
+        by_mem = int((0.8 * mem / mem_share - fixed) // (0.25 * field_bytes * ntols))
     # (planes_per_field: 1 byte per element and plane, encoder and decoder context of a lane each hold a field's planes)
     # an encoder's planes drain as its coder advances (half of them are gone on average), a decoder's stay until its field is
     # done: 0.75 of the two contexts' worst case; a call that finds no room for a plane waits for chunks to come back
     by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((0.75 * planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
     jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / mem_share / 2 ** 30, 1) if mem else None,
-                  "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm}
+                  "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm,
+                  "host_pages_of_consumed_streams_dropped": trim}
 
 
 def cpu_model():
@@ -334,6 +341,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jobs", type=int, default=16, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
     ap.add_argument("--fields-per-cpu", type=float, default=2.0, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
+    ap.add_argument("--trim-host", action="store_true", help="hand the pages of consumed coded streams back to the system (done by itself when host memory is what limits the lanes)")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
@@ -405,6 +413,7 @@ def main():
                             pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev, nslots=args.slots or 3,
                             planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
     limits["cpu_affinity_share"] = share
+    trim_host = bool(limits.get("host_pages_of_consumed_streams_dropped")) or args.trim_host
     pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
     if pool_workers:
         api.set_coder_pool(pool_workers, args.dec_streams)
@@ -464,6 +473,19 @@ def main():
         return diff / amax
 
     last_coded, last_decoded = {}, []
+    import ctypes
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def drop_pages(buf, used):
+        """Hands the pages of a consumed coded stream back to the system (MADV_DONTNEED: they read as zeros and are taken
+        again when the buffer is written next).  A hand-over buffer would otherwise keep the 2 GB of the largest field it
+        has ever held resident: 4 GiB per lane, two thirds of what a rank holds in host memory."""
+        a = (buf.ctypes.data + 4095) & ~4095
+        e = (buf.ctypes.data + int(used)) & ~4095
+        if e - a >= (64 << 20):
+            libc.madvise(a, e - a, 4)
+
     stats = {t: {} for t in tols}
     keys = ("fwd_ms", "inv_ms", "quant_ms", "dequant_ms", "minmax_ms", "enc_s", "dec_s", "enc_rc_s", "dec_rc_s", "enc_gpu_s",
             "dec_gpu_s", "enc_wait_s", "dec_wait_s", "enc_h2d_ms", "enc_d2h_ms", "dec_h2d_ms", "dec_d2h_ms", "nlay")
@@ -529,7 +551,9 @@ def main():
                         enc, te, tol, i = item
                         if host_mode:
                             ln["dec"].decode_begin(shape, enc)       # host range decoding: seconds, no field buffer
-                            free[k & 1].release()                    # the coded stream is not needed any more
+                            if trim_host and not (record and i >= total - len(tols)):
+                                drop_pages(ln["data"][k & 1], enc["ntot_enc"])  # the coded stream is not needed any more: its pages go back
+                            free[k & 1].release()
                             out = out_pool.get()
                             keep = False
                             try:
