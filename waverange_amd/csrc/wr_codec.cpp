@@ -291,6 +291,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     if (!fld.dev && !fld.host) return fail(WR_ERR_ARG, "null field pointer");
     if (cut.mx < 1 || cut.my < 1 || cut.mz < 1 || !cut.vec) return fail(WR_ERR_ARG, "bad local cutoff description");
     std::lock_guard<std::mutex> lk(c->mu);
+    ActiveCall active(c->pool);
     if (tm) wrdma::enable_timing();
     const double t0 = now();
     const size_t n = (size_t)nx * ny * nz;
@@ -398,6 +399,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         };
         {
             // ---- stage "kernels"
+            stage_gather(pool);
             cu.lock();
             rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, info, &local, after_quant, plane_ready, &resid);
             (void)hipStreamSynchronize(c->stream);
@@ -407,6 +409,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
                     rc = fail(WR_ERR_HIP, "residual copy failed");
             }
             cu.unlock();
+            stage_done(pool);
         }
         // ---- stage "down": the histograms were sent off as the planes completed; the residual follows them
         if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
@@ -493,6 +496,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
 {
     if (int rc = ctx_bind(c)) return rc;
     std::lock_guard<std::mutex> lk(c->mu);
+    ActiveCall active(c->pool);
     if (tm) wrdma::enable_timing();
     if (mode == kDecodeFinish) {
         if (!c->pend_valid) return fail(WR_ERR_ARG, "wr_decode_finish without a wr_decode_begin on this context");
@@ -624,10 +628,14 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         double* d_fld = fld.host ? slot->field : fld.dev;
         {
             // ---- stage "kernels"
-            StageLock cu(pool->cu_mu);
-            rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
-            if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
-            (void)hipStreamSynchronize(c->stream);
+            stage_gather(pool);
+            {
+                StageLock cu(pool->cu_mu);
+                rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
+                if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
+                (void)hipStreamSynchronize(c->stream);
+            }
+            stage_done(pool);
         }
         if (rc) return rc;
         if (fld.host) {

@@ -134,6 +134,13 @@ struct DevPool {
     int users = 0;
     hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
+    // A kernel stage that finds the GPU idle while many host calls are in flight on it (8 or more: a pipeline, not a lone
+    // caller) waits up to WR_STAGE_BATCH_MS (default 100) for a second stage to show up, so that the two run back to back and
+    // the second one finds the shader clock up (stage_gather)
+    std::mutex gate_mu; std::condition_variable gate_cv;
+    int gate_waiting = 0;
+    double gate_last_end = 0;
+    std::atomic<int> active_calls{0};  // wr_encode_* / wr_decode_* calls inside the library on this device
     DevPlanes planes;
 };
 
@@ -334,6 +341,15 @@ void transform_need(int nx, int ny, int nz, int lvl, SlotNeed* need);
 int run_transform(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int lvl, double** out);
 int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int nz, int wlev, const wrk::DequantParams& p);
 int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn, double* mx);
+struct ActiveCall {  // RAII: a codec call is inside the library
+    DevPool* p;
+    explicit ActiveCall(DevPool* pool) : p(pool) { p->active_calls++; }
+    ~ActiveCall() { p->active_calls--; }
+    ActiveCall(const ActiveCall&) = delete;
+    ActiveCall& operator=(const ActiveCall&) = delete;
+};
+void stage_gather(DevPool* p);     // before a host call's kernel stage takes cu_mu
+void stage_done(DevPool* p);       // after it has let go of it
 int check_dims(int nx, int ny, int nz, const void* dev_ptr);
 
 struct Sem {  // tiny counting semaphore limiting concurrent range-coder threads
