@@ -134,9 +134,9 @@ struct DevPool {
     int users = 0;
     hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
-    // A kernel stage that finds the GPU idle while many host calls are in flight on it (8 or more: a pipeline, not a lone
-    // caller) waits up to WR_STAGE_BATCH_MS (default 100) for a second stage to show up, so that the two run back to back and
-    // the second one finds the shader clock up (stage_gather)
+    // Measurement hook, off by default: with WR_STAGE_BATCH_MS=k a kernel stage that finds the GPU idle while many host calls
+    // are in flight on it (8 or more: a pipeline, not a lone caller) waits up to k ms for a second stage to show up, so that
+    // the two run back to back and the second one finds the shader clock up (stage_gather)
     std::mutex gate_mu; std::condition_variable gate_cv;
     int gate_waiting = 0;
     double gate_last_end = 0;

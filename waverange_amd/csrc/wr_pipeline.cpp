@@ -489,11 +489,13 @@ int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn
 
 // See DevPool.  The stages of the calls in flight are 8-22 ms long and arrive a few per second, so each one starts on a GPU
 // whose shader clock has fallen back; held back for a moment, two can run back to back.  Measured with 32
-// lanes (profiles/r03/ab_*): 150 ms -> the transforms 4.50 / 4.94 ms instead of 4.70 / 5.15 at the same whole-job rate;
-// 400 ms -> 4.46 / 4.90 ms and 9 % off the rate (a field that waits holds its lane).
+// lanes (profiles/r03/ab_*, ac_*): 150 ms at K = 8 -> the transforms 4.50 / 4.94 ms instead of 4.70 / 5.15 at the same whole-job
+// rate; 400 ms -> 4.46 / 4.90 ms and 9 % off the rate; 100 ms at the driver's K = 20 -> 4.65 / 5.07 ms (0.505 instead of 0.496
+// of peak) and 14.7 instead of 15.8 GB/s: a stage that waits holds its work-space slot and its field its lane, and a
+// transform that is 4 % faster moves nothing else.  Off by default (WR_STAGE_BATCH_MS=0).
 void stage_gather(DevPool* p)
 {
-    static const double window = getenv("WR_STAGE_BATCH_MS") ? atof(getenv("WR_STAGE_BATCH_MS")) * 1e-3 : 0.1;
+    static const double window = getenv("WR_STAGE_BATCH_MS") ? atof(getenv("WR_STAGE_BATCH_MS")) * 1e-3 : 0.0;
     if (window <= 0 || p->active_calls.load() < 8) { std::lock_guard<std::mutex> lk(p->gate_mu); p->gate_waiting++; p->gate_cv.notify_all(); return; }
     std::unique_lock<std::mutex> lk(p->gate_mu);
     p->gate_waiting++;
