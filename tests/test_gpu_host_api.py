@@ -533,6 +533,23 @@ def caller(k):
         errs.append(exc)
 if os.environ.get("POOL"):
     api.set_coder_pool(4, 4)
+else:
+    # the verbose mode looks at every plane again after it has been coded (wrappers.cpp:401-409): planes do not drain then,
+    # and the diagnostics read them chunk by chunk
+    api.set_verbosity(1)
+    with api.Context(0) as c:
+        enc, _ = c.encode_host(fields[0], 1e-8)
+        assert np.array_equal(enc["data"], want[0]["data"]), "verbose mode: coded bytes"
+        out = np.empty_like(fields[0]); enc["data"] = enc["data"].copy()
+        c.decode_host(out, enc)
+        assert bits_equal(out, recs[0]), "verbose mode: reconstruction"
+    api.set_verbosity(0)
+    # the local-cutoff quantizer scatters into its plane: that plane is one array whatever its size
+    cut = np.array([1e-8, 1e-6, 1e-7, 1e-8, 1e-5, 1e-8, 1e-7, 1e-6])
+    wl = o.encode(fields[1], None, cutoff=cut, m=(2, 2, 2))
+    with api.Context(0) as c:
+        enc, _ = c.encode_host(fields[1], None, cutoff=cut, m=(2, 2, 2))
+        assert enc["len_enc_vec"] == wl["len_enc_vec"] and np.array_equal(enc["data"], wl["data"]), "local cutoff: coded bytes"
 ths = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
 for t in ths: t.start()
 for t in ths: t.join()
