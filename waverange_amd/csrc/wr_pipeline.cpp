@@ -237,6 +237,11 @@ DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::
                 return false; }()) {
             const DevPlanes::Buf b = dp.take(bytes);
             if (b.p) return b;
+        } else {
+            // over the cap with idle buffers of other sizes lying around (another field size before): they make room
+            bool any_idle;
+            { std::lock_guard<std::mutex> lk(dp.mu); any_idle = !dp.idle.empty(); }
+            if (any_idle) { dp.drop_idle(); continue; }
         }
         if (unlock_while_waiting && !*unlocked) {
             (void)hipStreamSynchronize(c->stream);  // what this call has queued must not straddle the gap in its kernel stage
