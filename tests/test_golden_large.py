@@ -3,7 +3,7 @@ tools/make_golden_large.py from oracle/_ref in the build container): 512^3 (BASE
 (configs[2]) -- plane streams far past 2^24 bytes, where rngcod13's 24-bit length trailer wraps
 (src/rangecod/rangecod.c:254-276), 17 896 coding blocks per plane.
 
-CPU: the oracle restatement against the pins (512^3 always; 1024^3 with WR_GOLDEN_1024=1: ~6 minutes, 20 GiB).
+CPU: the oracle restatement against the pins (512^3 always; 1024^3 with WR_GOLDEN_1024=1: ~10 minutes, 40 GiB).
 GPU: the product, through the C ABI, against the pins -- on per-call coder threads AND on the configuration bench.py
 times (coder pool of 16, AVX-512 encoder and decoder sessions, windowed planes, two-call decode)."""
 import os
@@ -61,7 +61,7 @@ def test_oracle_equals_the_reference_at_512(oracle):
     oracle_vs_pins(oracle, 512, [t for _, t in CASES_512])
 
 
-@pytest.mark.skipif(not os.environ.get("WR_GOLDEN_1024"), reason="minutes of CPU and 20 GiB: WR_GOLDEN_1024=1 (log of a run: profiles/r03/)")
+@pytest.mark.skipif(not os.environ.get("WR_GOLDEN_1024"), reason="ten minutes of CPU and 40 GiB: WR_GOLDEN_1024=1 (log of a run: profiles/r03/oracle_vs_reference_pins_1024.log)")
 def test_oracle_equals_the_reference_at_1024(oracle):
     oracle_vs_pins(oracle, 1024, [t for _, t in CASES_1024])
 
