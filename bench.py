@@ -160,7 +160,7 @@ def take_cpu_share(local_rank, gpus_on_node):
         return None
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=2.0):
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=2.0, host_mem=None):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -181,16 +181,17 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # host memory like the CPUs: a rank sizes itself to its GPU's share of the node whether 1 or 8 ranks run, so that
     # the per-GPU work does not change with N (weak scaling measures GPUs, not how much idle memory one rank can borrow)
     mem_share = max(local_world, gpus_on_node if pinned_share else 1)
-    mem = None
-    try:
-        with open("/proc/meminfo") as fh:
-            mem = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]
-    except (OSError, IndexError):
-        pass
-    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):  # cgroup v2, v1
-        m = _cgroup_number(path)
-        if m and m[0] != "max" and int(m[0]) < 1 << 60:
-            mem = min(mem, int(m[0])) if mem else int(m[0])
+    mem = host_mem  # (given: tests)
+    if mem is None:
+        try:
+            with open("/proc/meminfo") as fh:
+                mem = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]
+        except (OSError, IndexError):
+            pass
+        for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):  # cgroup v2, v1
+            m = _cgroup_number(path)
+            if m and m[0] != "max" and int(m[0]) < 1 << 60:
+                mem = min(mem, int(m[0])) if mem else int(m[0])
     # 2 coder threads per field; an encoder thread idles a third of the time (decoding takes longer and
     # sets the period of a lane), hence 1.25 threads per CPU
     # with the coder pool the lanes are not threads: a field in flight spends part of its time in copies and kernels and
