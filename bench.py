@@ -343,6 +343,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=16, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
     ap.add_argument("--fields-per-cpu", type=float, default=2.0, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
     ap.add_argument("--trim-host", action="store_true", help="hand the pages of consumed coded streams back to the system (done by itself when host memory is what limits the lanes)")
+    ap.add_argument("--timeline", type=str, default=None, help="write what the coder pool did every half second of the timed region to this file (fill and drain of a run)")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
     ap.add_argument("--threads", type=int, default=1, help="range-coder threads per decode call; planes are interleaved when fewer than planes")
     ap.add_argument("--enc-threads", type=int, default=0, help="range-coder threads per encode call (0: as --threads; 2 was measured: no gain once the cores are full)")
@@ -612,10 +613,32 @@ def main():
     cpu0 = sum(os.times()[:2])
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
     loops0 = api.pool_loop_stats()
+    sampler = stop_sampling = None
+    if args.timeline and rank == 0:
+        stop_sampling = threading.Event()
+
+        def sample():
+            # workers busy per loop kind and symbols per second over every half second, fields begun so far
+            with open(args.timeline, "w") as fh:
+                fh.write("# t_s  idle_workers  " + "  ".join("%s(workers,Gsym/s)" % k for k in api.pool_loop_stats()) + "  fields_done\n")
+                tp, ip, lp = time.perf_counter(), api.stat(api.STAT_POOL_IDLE_MS), api.pool_loop_stats()
+                while not stop_sampling.wait(0.5):
+                    tn, inow, ln = time.perf_counter(), api.stat(api.STAT_POOL_IDLE_MS), api.pool_loop_stats()
+                    w = tn - tp
+                    cols = ["%5.2f,%5.2f" % ((ln[k][0] - lp[k][0]) / w, (ln[k][1] - lp[k][1]) * 6e-5 / w) for k in ln]
+                    fh.write("%7.2f  %5.2f  %s  %d\n" % (tn - t0, (inow - ip) * 1e-3 / w, "  ".join(cols), len(acc["nlay"])))
+                    fh.flush()
+                    tp, ip, lp = tn, inow, ln
+        sampler = threading.Thread(target=sample, daemon=True)
     t0 = time.perf_counter()
+    if sampler:
+        sampler.start()
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    if sampler:
+        stop_sampling.set()
+        sampler.join()
     cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
     pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
     loops1 = api.pool_loop_stats()

@@ -382,3 +382,57 @@ def test_streams_change_workers_same_bytes(oracle):
             assert moved > 0, "no stream ever changed workers"
     finally:
         api.set_coder_pool(0)
+
+
+SMALL_SESSIONS = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from waverange_amd import api
+from oracle.loader import Oracle
+o = Oracle()
+rs = np.random.RandomState(17)
+lens = (60000 * 5 + 17, 60000 * 3, 60000 * 7 + 59999, 60000 * 4 + 1, 60000 * 6)
+planes = [rs.choice(np.array([127, 128], np.uint8), size=lens[0], p=[0.8, 0.2]),
+          np.where(rs.random_sample(lens[1]) < 0.999, 255, rs.randint(0, 256, lens[1])).astype(np.uint8),
+          rs.randint(0, 256, lens[2]).astype(np.uint8),
+          rs.choice(np.array([3, 4, 5, 250], np.uint8), size=lens[3]),
+          np.full(lens[4], 9, np.uint8)]
+want = [o.range_encode(p) for p in planes]
+if api.lib().wr_range_decode_vec(0, None, None, None, None, None) != 0:
+    print("no AVX-512"); sys.exit(0)
+for k in (1, 2, 3, 4, 5):   # sessions of 1 .. 5 streams that shrink to nothing as the planes end one after the other
+    for first in range(len(planes)):
+        sel = [(first + j) %% len(planes) for j in range(k)]
+        enc = api.range_encode_vec([planes[i] for i in sel])
+        for i, e in zip(sel, enc):
+            assert np.array_equal(e, want[i]), ("encode", k, i)
+        for any_stat in (False, True):
+            dec, got = api.range_decode_vec([want[i] for i in sel], [planes[i].size for i in sel], any_statistics=any_stat)
+            for i, d, g in zip(sel, dec, got):
+                assert g == planes[i].size and np.array_equal(d, planes[i]), ("decode", any_stat, k, i)
+n = 60000 * 2 + 54321
+ps = [p[:n] for p in planes[:3]]
+ws = [o.range_encode(p) for p in ps]
+for mode in (2, 3):         # the same through windows of two blocks (planes in device memory reach the coder that way)
+    enc = api.range_encode_windowed(ps, 120000, 2)
+    dec, got = api.range_decode_windowed(ws, n, 120000, mode)
+    for a, b, d, g, p in zip(enc, ws, dec, got, ps):
+        assert np.array_equal(a, b) and g == n and np.array_equal(d, p), ("windowed", mode)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("small_scalar", ["1", "0"])
+def test_small_vector_sessions_same_bytes(small_scalar):
+    """A 16-lane session that is down to three streams or fewer runs them through the scalar interleaved loops
+    (wr_rangecoder.cpp, kSmallScalar; WR_VEC_SMALL_SCALAR=0: the vector loop whatever the count).  Both ways, in a child
+    process each (the switch is read once): sessions of 1-5 planes of all kinds and lengths -- the streams change loops in
+    mid-plane as their neighbours end -- must give the oracle's bytes and symbols, whole planes and windowed ones."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WR_VEC_SMALL_SCALAR=small_scalar)
+    out = subprocess.run([sys.executable, "-c", SMALL_SESSIONS % root], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] in ("ok", "no AVX-512")

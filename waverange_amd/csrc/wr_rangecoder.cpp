@@ -315,42 +315,47 @@ public:
     }
     // one block of every stream; on_end(tag, stream length) for the streams that ended with it
     template <class OnEnd>
-    void step(OnEnd on_end)
+    void step(OnEnd on_end) { step_streams(count_, es_, store_, st_, tabs_, tops_, on_end); }
+    // the same on the slots of another holder of at most kMaxEncStreams streams (a 16-lane session that is down to a few)
+    template <class OnEnd>
+    static void step_streams(int& count, Enc** es, unsigned char (*store)[sizeof(Enc)], Stream* st, SymEntry (*tabs)[256], uint32_t* tops,
+                             OnEnd on_end)
     {
         uint32_t bs[kMaxEncStreams];
+        const uint8_t* ss[kMaxEncStreams];
         bool all_full = true, topsel = false;  // topsel: some plane's largest symbol holds > 2 % of this block
-        for (int k = 0; k < count_; k++) {
-            Stream& s = st_[k];
+        for (int k = 0; k < count; k++) {
+            Stream& s = st[k];
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
-            ss_[k] = s.sym.at(s.done, s.n);
-            encode_block_header(*es_[k], ss_[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
+            ss[k] = s.sym.at(s.done, s.n);
+            encode_block_header(*es[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs[k], &tops[k]);
             all_full = all_full && bs[k] == kBlock;
-            topsel = topsel || (uint64_t)tabs_[k][tops_[k]].sy * 50 > bs[k];
+            topsel = topsel || (uint64_t)tabs[k][tops[k]].sy * 50 > bs[k];
         }
         if (all_full) {
-            switch (count_) {
-            case 1: topsel ? encode_symbols<kBlock, true>(*es_[0], ss_[0], kBlock, tabs_[0], tops_[0]) : encode_symbols<kBlock, false>(*es_[0], ss_[0], kBlock, tabs_[0], tops_[0]); break;
-            case 2: topsel ? encode_symbols_multi<2, true>(es_, ss_, tabs_, tops_) : encode_symbols_multi<2, false>(es_, ss_, tabs_, tops_); break;
-            default: topsel ? encode_symbols_multi<3, true>(es_, ss_, tabs_, tops_) : encode_symbols_multi<3, false>(es_, ss_, tabs_, tops_); break;
+            switch (count) {
+            case 1: topsel ? encode_symbols<kBlock, true>(*es[0], ss[0], kBlock, tabs[0], tops[0]) : encode_symbols<kBlock, false>(*es[0], ss[0], kBlock, tabs[0], tops[0]); break;
+            case 2: topsel ? encode_symbols_multi<2, true>(es, ss, tabs, tops) : encode_symbols_multi<2, false>(es, ss, tabs, tops); break;
+            default: topsel ? encode_symbols_multi<3, true>(es, ss, tabs, tops) : encode_symbols_multi<3, false>(es, ss, tabs, tops); break;
             }
         } else {
-            for (int k = 0; k < count_; k++) {
-                if (bs[k] == kBlock) encode_symbols<kBlock, true>(*es_[k], ss_[k], kBlock, tabs_[k], tops_[k]);
-                else if (bs[k]) encode_symbols<0, true>(*es_[k], ss_[k], bs[k], tabs_[k], tops_[k]);
+            for (int k = 0; k < count; k++) {
+                if (bs[k] == kBlock) encode_symbols<kBlock, true>(*es[k], ss[k], kBlock, tabs[k], tops[k]);
+                else if (bs[k]) encode_symbols<0, true>(*es[k], ss[k], bs[k], tabs[k], tops[k]);
             }
         }
-        for (int k = 0; k < count_;) {
-            st_[k].done += bs[k];
-            st_[k].blk++;
+        for (int k = 0; k < count;) {
+            st[k].done += bs[k];
+            st[k].blk++;
             if (bs[k] == kBlock) { k++; continue; }
-            es_[k]->freq(1, 0, 2);  // "no more blocks"
-            on_end(st_[k].tag, es_[k]->finish());
+            es[k]->freq(1, 0, 2);  // "no more blocks"
+            on_end(st[k].tag, es[k]->finish());
             // the last slot moves into the hole (its block size with it: it has not been looked at yet)
-            const int last = --count_;
+            const int last = --count;
             if (k != last) {
-                es_[k] = new (store_[k]) Enc(*es_[last]);
-                st_[k] = st_[last];
+                es[k] = new (store[k]) Enc(*es[last]);
+                st[k] = st[last];
                 bs[k] = bs[last];
             }
         }
@@ -363,8 +368,14 @@ private:
     Stream st_[kMaxEncStreams];
     SymEntry tabs_[kMaxEncStreams][256];
     uint32_t tops_[kMaxEncStreams];
-    const uint8_t* ss_[kMaxEncStreams];
 };
+
+// A 16-lane session that holds no more streams than a scalar loop takes runs them through that loop (WR_VEC_SMALL_SCALAR=0:
+// never): per stream and per thread it is the faster one there (EPYC 9575F, dominant-symbol planes, Msym/s per stream:
+// encoder 1 / 2 / 3 streams scalar ~300 / ~250 / 190 against ~110 in the vector loop at <= 4 lanes; decoder 304 / 214 / 142
+// against ~110).  Sessions get that small when a run fills or drains, with a lone caller, and after idle workers have taken
+// over half of a session's streams.
+const bool kSmallScalar = !(getenv("WR_VEC_SMALL_SCALAR") && !atoi(getenv("WR_VEC_SMALL_SCALAR")));
 
 }  // namespace
 
@@ -410,6 +421,7 @@ public:
     template <class OnEnd>
     void step(OnEnd on_end)
     {
+        if (kSmallScalar && count_ <= kMaxEncStreams) { EncGroup::step_streams(count_, es_, store_, st_, tabs_, tops_, on_end); return; }
         uint32_t bs[kCap];
         VecEncBlock vb;
         vb.active = 0;
@@ -671,6 +683,8 @@ constexpr uint16_t kMixed = 0x100;
 #define WR_RC_MPS_PCT 90
 #endif
 
+const uint32_t kMixedPct = getenv("WR_RC_MIXED_PCT") ? (uint32_t)atoi(getenv("WR_RC_MIXED_PCT")) : WR_RC_MIXED_PCT;
+
 // the look-up side of a block model (60 KB + buckets): what the division path needs
 void finish_model_tables(BlockModel& m)
 {
@@ -684,7 +698,7 @@ void finish_model_tables(BlockModel& m)
         m.bucket[j] = (a == z) ? a : kMixed;  // symbols ascend with the cumulative frequency: equal ends = equal throughout
         if (a != z && lo < m.bs) mixed += 1u << kBucketShift;
     }
-    m.use_buckets = (uint64_t)mixed * 100 < (uint64_t)m.bs * WR_RC_MIXED_PCT;
+    m.use_buckets = (uint64_t)mixed * 100 < (uint64_t)m.bs * kMixedPct;
     m.tables_ready = true;
 }
 
@@ -1064,6 +1078,7 @@ public:
     {
         constexpr size_t kMargin = 3 * (size_t)kBlock + 32;  // a symbol pulls in at most 3 bytes; the vector loop reads two windows ahead
         bool vec[kCap];
+        bool all_fast = true;
         for (int k = 0; k < count_;) {
             Dec& d = *ds_[k];
             BlockModel& m = *ms_[k];
@@ -1095,9 +1110,19 @@ public:
             }
             const bool fast = m.bs == kBlock && cur_[k].room(at) >= kBlock && d.pos + kMargin <= d.len;
             vec[k] = fast && (any_ || m.cand_ok);
+            all_fast = all_fast && fast;
             k++;
         }
         if (!count_) return;
+        if (kSmallScalar && all_fast && count_ < kMaxDecStreams) {  // down to a few streams: the scalar loop of up to three (kSmallScalar)
+            for (int k = 0; k < count_; k++) {
+                if (any_) finish_model_stats(*ms_[k]);
+                if (!ms_[k]->tables_ready) finish_model_tables(*ms_[k]);
+            }
+            decode_block_multi(count_, ds_, dst_, ms_);
+            for (int k = 0; k < count_; k++) produced_[k] += kBlock;
+            return;
+        }
         if (any_) { step_any(vec); finish_slow(vec, on_end); return; }
         VecBlock vb;
         vb.active = 0;
