@@ -143,18 +143,90 @@ def _cgroup_number(path):
         return None
 
 
-def take_cpu_share(local_rank, gpus_on_node):
-    """Pin this process (and the threads it starts later) to its GPU's share of the host CPUs: 1 / gpus_on_node
-    of the CPUs it may run on, the local_rank-th slice.  A rank then has the same host behind its GPU
-    whether 1 or 8 ranks run on the node (weak scaling measures GPUs, not how many idle cores one rank can
-    borrow).  No-op with a single visible GPU or when anything about it fails."""
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def read_cpu_topology(gpu_bdfs=()):
+    """What cpu_share_of needs, from sysfs: the CPUs this process may run on, the hardware threads that share a core with
+    each of them, the NUMA node of every CPU and of every GPU (PCI address "dddd:bb:dd.f"; -1: unknown)."""
+    import glob
+    allowed = sorted(os.sched_getaffinity(0))
+    siblings, node_of_cpu = {}, {}
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as fh:
+                siblings[c] = tuple(_cpulist(fh.read()))
+        except (OSError, ValueError):
+            siblings[c] = (c,)
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try:
+            with open(d + "/cpulist") as fh:
+                for c in _cpulist(fh.read()):
+                    node_of_cpu[c] = int(d.rsplit("node", 1)[1])
+        except (OSError, ValueError):
+            pass
+    gpu_nodes = []
+    for bdf in gpu_bdfs:
+        try:
+            with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as fh:
+                gpu_nodes.append(int(fh.read().strip()))
+        except (OSError, ValueError):
+            gpu_nodes.append(-1)
+    return {"allowed": allowed, "siblings": siblings, "node_of_cpu": node_of_cpu, "gpu_nodes": gpu_nodes}
+
+
+def cpu_share_of(local_rank, gpus_on_node, topo):
+    """The CPUs of GPU `local_rank`'s share of the host: whole physical cores (all their hardware threads: two ranks never
+    meet on one core), 1 / gpus_on_node of them -- taken from the GPU's own NUMA node when the nodes of all GPUs are known,
+    split evenly among the GPUs of that node; otherwise the local_rank-th slice of all cores.  None: the CPU set is too
+    small to have been sized for the node (< 8 CPUs per GPU), or a single GPU."""
+    allowed = set(topo["allowed"])
+    if gpus_on_node < 2 or len(allowed) // gpus_on_node < 8:
+        return None
+    cores = sorted({tuple(sorted(c for c in topo["siblings"].get(cpu, (cpu,)) if c in allowed)) for cpu in allowed})
+    d = local_rank % gpus_on_node
+    gpu_nodes = list(topo.get("gpu_nodes") or [])[:gpus_on_node]
+    node_of = topo.get("node_of_cpu") or {}
+    even = len(cores) // gpus_on_node
+    mine = None
+    if len(gpu_nodes) == gpus_on_node and all(g >= 0 for g in gpu_nodes):
+        # by node -- for all GPUs or for none: every node must give each of its GPUs at least half of an even share
+        # (else: a CPU set that was cut down without regard to the nodes)
+        plan = []
+        for g in range(gpus_on_node):
+            peers = [h for h in range(gpus_on_node) if gpu_nodes[h] == gpu_nodes[g]]
+            local = [cs for cs in cores if node_of.get(cs[0], -1) == gpu_nodes[g]]
+            per = len(local) // len(peers)
+            plan.append(local[peers.index(g) * per:(peers.index(g) + 1) * per])
+        if all(len(p) >= max(1, even // 2) for p in plan):
+            mine = plan[d]
+    if mine is None:
+        mine = cores[d * even:(d + 1) * even]
+    cpus = sorted(c for cs in mine for c in cs)
+    return cpus or None
+
+
+def take_cpu_share(local_rank, gpus_on_node, gpu_bdfs=()):
+    """Pin this process -- the threads it has (runtime helpers) and the ones it starts later -- to its GPU's share of the
+    host CPUs (cpu_share_of).  A rank then has the same host behind its GPU whether 1 or 8 ranks run on the node (weak
+    scaling measures GPUs, not how many idle cores one rank can borrow), never shares a physical core with another rank,
+    and codes on the memory of its GPU's NUMA node.  No-op with a single visible GPU or when anything about it fails."""
     try:
-        allowed = sorted(os.sched_getaffinity(0))
-        share = len(allowed) // max(1, gpus_on_node)
-        if gpus_on_node < 2 or share < 8:  # a CPU set this small was sized for the job, not for the node
+        mine = cpu_share_of(local_rank, gpus_on_node, read_cpu_topology(gpu_bdfs))
+        if not mine:
             return None
-        mine = allowed[(local_rank % gpus_on_node) * share:(local_rank % gpus_on_node + 1) * share]
         os.sched_setaffinity(0, mine)
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), mine)
+            except OSError:
+                pass
         return len(mine)
     except (OSError, ValueError, AttributeError):
         return None
@@ -410,7 +482,13 @@ def main():
 
     # How many fields in flight this rank can afford (fit_jobs): its share of the CPUs, of the host memory (coded
     # streams) and the free HBM (the quantized planes of the fields in flight live there).  --jobs is the upper bound.
-    share = take_cpu_share(local_rank, ndev) if backend == "nccl" else None
+    share = None
+    if backend == "nccl":
+        bdfs = []
+        for d in range(ndev):
+            pr = torch.cuda.get_device_properties(d)
+            bdfs.append("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        share = take_cpu_share(local_rank, ndev, bdfs)
     jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
                             pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev, nslots=args.slots or 3,
                             planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)

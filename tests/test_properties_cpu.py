@@ -99,3 +99,43 @@ def test_bench_cpu_share_pinning():
     else:
         assert share == "None"  # fewer than 8 CPUs per GPU: left alone
     assert out[1] == "None"  # a single visible GPU: nothing to share
+
+
+def test_bench_cpu_share_follows_cores_and_numa_nodes():
+    """cpu_share_of on the topology of the MI355X boxes of this pool (profiles/r03/ao_cpu_probe_gpu_box.txt: 2 x 64 cores,
+    hardware threads c and c + 128 share a core, node 0 = cores 0-63, node 1 = cores 64-127, four GPUs on either node):
+    every rank gets whole cores of its GPU's node, no two ranks meet on a core, all CPUs are handed out; without the
+    GPUs' nodes it falls back to slices of whole cores; small CPU sets and single GPUs are left alone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    allowed = list(range(256))
+    topo = {"allowed": allowed, "siblings": {c: (c % 128, c % 128 + 128) for c in allowed},
+            "node_of_cpu": {c: (c % 128) // 64 for c in allowed}, "gpu_nodes": [0, 0, 1, 1, 0, 1, 1, 0]}
+    shares = [bench.cpu_share_of(r, 8, topo) for r in range(8)]
+    seen = set()
+    for r, cpus in enumerate(shares):
+        assert len(cpus) == 32 and not seen & set(cpus)
+        seen |= set(cpus)
+        cores = {c % 128 for c in cpus}
+        assert len(cores) == 16 and all(c % 128 + 128 in cpus and c % 128 in cpus for c in cpus)  # whole cores
+        assert {topo["node_of_cpu"][c] for c in cpus} == {topo["gpu_nodes"][r]}                   # on the GPU's node
+    assert seen == set(allowed)
+    # one rank alone on the node takes the same share as with eight (weak scaling: the host behind a GPU does not change)
+    assert bench.cpu_share_of(0, 8, topo) == shares[0]
+    # nodes unknown: slices of whole cores in device order
+    blind = dict(topo, gpu_nodes=[-1] * 8)
+    got = [bench.cpu_share_of(r, 8, blind) for r in range(8)]
+    assert got[0] == sorted(list(range(0, 16)) + list(range(128, 144))) and got[7] == sorted(list(range(112, 128)) + list(range(240, 256)))
+    assert sorted(c for g in got for c in g) == allowed
+    # all GPUs on one node of a two-node host whose CPU set spans both: that node's cores are split among them
+    onenode = dict(topo, gpu_nodes=[1] * 8)
+    got = [bench.cpu_share_of(r, 8, onenode) for r in range(8)]
+    assert all(len(g) == 16 and {topo["node_of_cpu"][c] for c in g} == {1} for g in got) and len({c for g in got for c in g}) == 128
+    # a CPU set that was cut down without regard to the nodes (all of it on node 0, GPU on node 1): plain slices
+    cut = {"allowed": list(range(32)), "siblings": {c: (c,) for c in range(32)}, "node_of_cpu": {c: 0 for c in range(32)}, "gpu_nodes": [0, 1]}
+    assert bench.cpu_share_of(1, 2, cut) == list(range(16, 32)) and bench.cpu_share_of(0, 2, cut) == list(range(16))
+    # too few CPUs per GPU, or one GPU: left alone
+    assert bench.cpu_share_of(0, 8, {"allowed": list(range(32)), "siblings": {}, "node_of_cpu": {}, "gpu_nodes": []}) is None
+    assert bench.cpu_share_of(0, 1, topo) is None
