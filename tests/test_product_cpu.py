@@ -436,3 +436,58 @@ def test_small_vector_sessions_same_bytes(small_scalar):
     out = subprocess.run([sys.executable, "-c", SMALL_SESSIONS % root], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] in ("ok", "no AVX-512")
+
+
+DUAL_GROUPS = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from waverange_amd import api
+from oracle.loader import Oracle
+o = Oracle()
+if api.lib().wr_range_decode_vec(0, None, None, None, None, None) != 0:
+    print("no AVX-512"); sys.exit(0)
+rs = np.random.RandomState(23)
+planes = []
+for k in range(37):   # more than two groups hold; lengths around block boundaries, streams leave one after the other
+    n = 60000 * (2 + k %% 5) + (0, 1, 59999, 777)[k %% 4]
+    kind = k %% 4
+    if kind == 0:
+        planes.append(rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.8, 0.2]))
+    elif kind == 1:
+        planes.append(np.where(rs.random_sample(n) < 0.9997, 128, rs.randint(120, 136, n)).astype(np.uint8))
+    elif kind == 2:
+        planes.append(rs.choice(np.array([0, 254, 255], np.uint8), size=n, p=[0.05, 0.05, 0.9]))
+    else:
+        planes.append(rs.randint(0, 256, n).astype(np.uint8))   # noise: every block falls back to the scalar loop of its lane
+want = [o.range_encode(p) for p in planes]
+dec, got = api.range_decode_vec(want, [p.size for p in planes])
+for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+    assert g == p.size and np.array_equal(d, p), ("hook", i)
+api.set_coder_pool(2, 4)
+try:
+    for rep in range(2):
+        dec, got = api.range_decode_pool(want, [p.size for p in planes])
+        for i, (d, g, p) in enumerate(zip(dec, got, planes)):
+            assert g == p.size and np.array_equal(d, p), ("pool", rep, i)
+        n = 60000 * 3 + 4321
+        ps = [p[:n] for p in planes if p.size >= n][:20]
+        ws = [o.range_encode(p) for p in ps]
+        dec, got = api.range_decode_windowed(ws, n, 120000, 2)
+        for i, (d, g, p) in enumerate(zip(dec, got, ps)):
+            assert g == n and np.array_equal(d, p), ("windowed", rep, i)
+finally:
+    api.set_coder_pool(0)
+print("ok")
+"""
+
+
+def test_two_decoder_groups_per_session_same_symbols():
+    """WR_VEC_DUAL=1 (opt-in): a vector decoder session holds two 16-lane groups whose symbol loops run interleaved
+    (wr_rangecoder_avx512.cpp, vec_decode_block2).  37 planes of all kinds through the measurement hook, the pool and
+    windows: the oracle's symbols, whatever group a stream lands in and whenever its neighbours end."""
+    import sys
+    env = dict(os.environ, WR_VEC_DUAL="1")
+    out = subprocess.run([sys.executable, "-c", DUAL_GROUPS % ROOT], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] in ("ok", "no AVX-512")

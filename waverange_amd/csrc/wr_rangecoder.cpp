@@ -376,6 +376,8 @@ private:
 // against ~110).  Sessions get that small when a run fills or drains, with a lone caller, and after idle workers have taken
 // over half of a session's streams.
 const bool kSmallScalar = !(getenv("WR_VEC_SMALL_SCALAR") && !atoi(getenv("WR_VEC_SMALL_SCALAR")));
+// two 16-lane groups per vector session, their symbol loops interleaved (DualVecDecGroup)
+const bool kVecDual = getenv("WR_VEC_DUAL") && atoi(getenv("WR_VEC_DUAL"));
 
 }  // namespace
 
@@ -1076,9 +1078,22 @@ public:
     template <class OnEnd>
     void step(OnEnd on_end)
     {
+        VecBlock vb;
+        if (!prepare(on_end, vb)) return;
+        if (vb.active) vec_decode_block(&vb, vec_other_symbol);
+        finish(vb, on_end);
+    }
+    // A step in two halves, so that two groups can share one symbol loop (DualVecDecGroup).  prepare: block headers of
+    // all streams (streams that end leave), the lanes of the vector loop in vb (vb.active may be 0); false: nothing left
+    // to do in this step (no streams, or they went through another loop already).  finish: lane state back to the
+    // streams, the other streams' blocks through the scalar loop.
+    template <class OnEnd>
+    bool prepare(OnEnd on_end, VecBlock& vb)
+    {
         constexpr size_t kMargin = 3 * (size_t)kBlock + 32;  // a symbol pulls in at most 3 bytes; the vector loop reads two windows ahead
-        bool vec[kCap];
+        bool* vec = vec_;
         bool all_fast = true;
+        vb.active = 0;
         for (int k = 0; k < count_;) {
             Dec& d = *ds_[k];
             BlockModel& m = *ms_[k];
@@ -1113,7 +1128,7 @@ public:
             all_fast = all_fast && fast;
             k++;
         }
-        if (!count_) return;
+        if (!count_) return false;
         if (kSmallScalar && all_fast && count_ < kMaxDecStreams) {  // down to a few streams: the scalar loop of up to three (kSmallScalar)
             for (int k = 0; k < count_; k++) {
                 if (any_) finish_model_stats(*ms_[k]);
@@ -1121,11 +1136,9 @@ public:
             }
             decode_block_multi(count_, ds_, dst_, ms_);
             for (int k = 0; k < count_; k++) produced_[k] += kBlock;
-            return;
+            return false;
         }
-        if (any_) { step_any(vec); finish_slow(vec, on_end); return; }
-        VecBlock vb;
-        vb.active = 0;
+        if (any_) { step_any(vec); finish_slow(vec, on_end); return false; }
         for (int k = 0; k < count_; k++) {
             if (!vec[k]) continue;
             const Dec& d = *ds_[k];
@@ -1138,17 +1151,22 @@ public:
             }
             vb.model[k] = &m;
         }
-        if (vb.active) {
+        if (vb.active)
             for (int k = 0; k < kCap; k++)
                 if (!(vb.active >> k & 1)) { for (int e = 0; e < kVecCand; e++) vb.is_top[e][k] = 0; vb.ptr[k] = nullptr; vb.dst[k] = nullptr; }
-            vec_decode_block(&vb, vec_other_symbol);
+        return true;
+    }
+    template <class OnEnd>
+    void finish(const VecBlock& vb, OnEnd on_end)
+    {
+        bool* vec = vec_;
+        if (vb.active)
             for (int k = 0; k < count_; k++) {
                 if (!vec[k]) continue;
                 Dec& d = *ds_[k];
                 d.low = vb.low[k]; d.range = vb.range[k]; d.pos = (size_t)(vb.ptr[k] - d.in); d.held = vb.ptr[k][-1];
                 produced_[k] += kBlock;
             }
-        }
         finish_slow(vec, on_end);
     }
 
@@ -1226,6 +1244,7 @@ private:
 
     struct FreeDeleter { void operator()(void* p) const { free(p); } };
     const bool any_;
+    bool vec_[kCap];  // this step: the stream's block goes through the vector loop
     std::unique_ptr<uint8_t, FreeDeleter> arena_;    // any_: [kCap][kAnyStride] symbol of every cumulative frequency
     std::unique_ptr<uint32_t, FreeDeleter> packed_;  // any_: [kCap][256] lt | sy << 16
     int count_ = 0;
@@ -1242,6 +1261,45 @@ private:
     std::vector<uint8_t> bounce_;  // decode_block_checked
 };
 
+// Two 16-lane groups of dominant-symbol planes whose symbol loops run interleaved on one thread (vec_decode_block2): the
+// second group's step fills the issue slots the first one's dependency chain leaves empty.  Streams go to the first
+// group while it has room, so that up to 16 streams run as one group.
+class DualVecDecGroup {
+public:
+    static constexpr int kCap = 2 * kVecLanes;
+    int count() const { return a_.count() + b_.count(); }
+    bool full() const { return a_.full() && b_.full(); }
+    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag, const PlaneWindow* io = nullptr)
+    {
+        last_ = a_.full() ? &b_ : &a_;
+        last_->add(in, len, sym, n, tag, io);
+    }
+    DecStream give() { return (b_.count() ? b_ : a_).give(); }
+    void take(DecStream&& m)
+    {
+        last_ = a_.full() ? &b_ : &a_;
+        last_->take(std::move(m));
+    }
+    void set_tag_of_last(void* t) { last_->set_tag_of_last(t); }
+    template <class OnEnd>
+    void step(OnEnd on_end)
+    {
+        VecBlock va, vb;
+        const bool ra = a_.prepare(on_end, va), rb = b_.prepare(on_end, vb);
+        if (ra && rb && va.active && vb.active) vec_decode_block2(&va, &vb, vec_other_symbol);
+        else {
+            if (ra && va.active) vec_decode_block(&va, vec_other_symbol);
+            if (rb && vb.active) vec_decode_block(&vb, vec_other_symbol);
+        }
+        if (ra) a_.finish(va, on_end);
+        if (rb) b_.finish(vb, on_end);
+    }
+
+private:
+    VecDecGroup a_, b_;
+    VecDecGroup* last_ = &a_;
+};
+
 }  // namespace
 
 // `count` streams of dominant-symbol planes (any lengths) on the calling thread through the 16-lane loop: test
@@ -1250,16 +1308,19 @@ bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, u
                        const PlaneWindow* const* io, bool any)
 {
     if (!vec_available()) return false;
-    std::unique_ptr<VecDecGroup> g(new VecDecGroup(any));
-    int next = 0;
-    while (next < count || g->count()) {
-        while (next < count && !g->full()) {
-            produced[next] = 0;
-            g->add(in[next], len[next], sym[next], n[next], produced + next, io ? io[next] : nullptr);
-            next++;
+    auto run = [&](auto& g) {
+        int next = 0;
+        while (next < count || g.count()) {
+            while (next < count && !g.full()) {
+                produced[next] = 0;
+                g.add(in[next], len[next], sym[next], n[next], produced + next, io ? io[next] : nullptr);
+                next++;
+            }
+            g.step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
         }
-        g->step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
-    }
+    };
+    if (kVecDual && !any) { std::unique_ptr<DualVecDecGroup> g(new DualVecDecGroup); run(*g); }
+    else { std::unique_ptr<VecDecGroup> g(new VecDecGroup(any)); run(*g); }
     return true;
 }
 
@@ -1408,6 +1469,7 @@ private:
     // owner packs them up (offer), the idle worker adopts them (next) -- same kind of loop, same bytes, the streams only
     // change threads between two blocks.  WR_POOL_STEAL=0 turns it off.
     struct Tag { PlaneJob* job; double t0; };
+    static constexpr int kSessionTags = 2 * kVecLanes;  // streams a session can hold (two 16-lane groups)
     struct Handoff {
         int kind = kAny;
         std::vector<DecStream> dec;
@@ -1493,7 +1555,7 @@ private:
         // live on by topping up from the queues stays what the caps say (they balance CPU time against the time a field
         // waits for its planes; a session that tops up never ends while jobs keep coming).
         const bool tops_up = j != nullptr;
-        auto free_tag = [&]() -> Tag* { for (int i = 0; i < kVecLanes; i++) if (!tags[i].job) return &tags[i]; return nullptr; };
+        auto free_tag = [&]() -> Tag* { for (int i = 0; i < kSessionTags; i++) if (!tags[i].job) return &tags[i]; return nullptr; };
         auto on_end = [](void* tag, size_t result) { Tag* t = static_cast<Tag*>(tag); finish(t->job, result, t->t0); t->job = nullptr; };
         for (size_t i = 0; i < h.tags.size(); i++) {
             Tag* t = free_tag();
@@ -1520,9 +1582,10 @@ private:
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
         std::unique_ptr<DecGroup> dg;
         std::unique_ptr<VecDecGroup> vg, vag;
+        std::unique_ptr<DualVecDecGroup> dvg;
         std::unique_ptr<VecEncGroup> veg;
         EncGroup eg;
-        Tag tags[kVecLanes];
+        Tag tags[kSessionTags];
         auto add_dec = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->src_len, j->dst, j->n, t, j->io); };
         auto add_enc = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->n, j->dst, j->hist, t, j->io); };
         auto adopt_dec = [](auto& g, Handoff& h, size_t i, Tag* t) { g.take(std::move(h.dec[i])); g.set_tag_of_last(t); };
@@ -1547,7 +1610,11 @@ private:
             if (!next(&kind, &j, &h)) return;
             for (Tag& t : tags) t.job = nullptr;
             const bool counted = j != nullptr;  // a session started from a queue counts against its kind's cap (pop)
-            if (kind == kVec) {
+            if (kind == kVec && kVecDual) {
+                if (!dvg) dvg.reset(new DualVecDecGroup);
+                session(id, kVec, 2, *dvg, j, h, tags, add_dec, adopt_dec, pack_dec);
+                session_over(id, counted ? &vec_sessions_ : nullptr);
+            } else if (kind == kVec) {
                 if (!vg) vg.reset(new VecDecGroup);
                 session(id, kVec, 2, *vg, j, h, tags, add_dec, adopt_dec, pack_dec);
                 session_over(id, counted ? &vec_sessions_ : nullptr);

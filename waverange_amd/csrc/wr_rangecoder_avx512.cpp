@@ -27,25 +27,16 @@ inline void transpose16x16(__m128i r[16])
 
 }  // namespace
 
-void vec_decode_block(VecBlock* b, VecOther other)
-{
-    const __mmask16 act = (__mmask16)b->active;
-    const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
-    // inactive lanes idle on a state that never renormalises and always "hits" candidate 0
-    __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
-    __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
+namespace {
+
+// The lanes of one VecBlock: state and one symbol step of all of them (rangecod.c:294-351 per lane).
+struct DecLanes {
+    VecBlock* b;
+    VecOther other;
+    __mmask16 act;
+    __m512i low, range, win, nxt, cnt;
     __m512i lt[kVecCand], sy[kVecCand], sym[kVecCand];
     __mmask16 top[kVecCand];
-    for (int e = 0; e < kVecCand; e++) {
-        lt[e] = _mm512_maskz_loadu_epi32(act, b->lt[e]);
-        sy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
-        sym[e] = _mm512_maskz_loadu_epi32(act, b->sym[e]);
-        top[e] = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[e]), _mm512_setzero_si512());
-    }
-    // floor(x / 60000) = ((x >> 5) * 146601551) >> 38 for every 32-bit x (checked exhaustively over x >> 5 < 2^27)
-    const __m512i magic = _mm512_set1_epi64(146601551);
-    const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
-
     // Byte feed.  The stream enters `low` as a bit string that starts 7 bits into the byte held back
     // (rangecod.c:297-299): the byte a lane shifts in at pointer q is ((q[-1] << 8 | q[0]) >> 1) & 0xff.  Every lane
     // keeps a window of the next four such bytes (top byte first), the count of those still unused, and the
@@ -55,23 +46,42 @@ void vec_decode_block(VecBlock* b, VecOther other)
     // dependency chain, which the whole-register update of a just-in-time reload would sit on.
     const uint8_t* pw[kVecLanes];  // stream position the lane's current window was loaded at
     uint8_t* d[kVecLanes];
-    alignas(64) uint32_t w0[kVecLanes], w1[kVecLanes];
-    auto window_at = [](const uint8_t* q) -> uint32_t {
+    __m128i rows[16];
+
+    static inline uint32_t window_at(const uint8_t* q)
+    {
         uint64_t v;
         __builtin_memcpy(&v, q - 1, 8);
         return (uint32_t)(__builtin_bswap64(v) >> 25);
-    };
-    for (int j = 0; j < kVecLanes; j++) {
-        pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = w1[j] = 0;
-        if (act >> j & 1) { w0[j] = window_at(pw[j]); w1[j] = window_at(pw[j] + 4); }
     }
-    __m512i win = _mm512_load_si512(w0), nxt = _mm512_load_si512(w1);
-    __m512i cnt = _mm512_set1_epi32(4);
-    const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
-    alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
-    __m128i rows[16];
-
-    for (uint32_t i = 0; i < kBlockSyms; i++) {
+    __attribute__((always_inline)) inline void init(VecBlock* blk, VecOther oth)
+    {
+        b = blk; other = oth;
+        act = (__mmask16)b->active;
+        // inactive lanes idle on a state that never renormalises and always "hits" candidate 0
+        low = _mm512_maskz_loadu_epi32(act, b->low);
+        range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
+        for (int e = 0; e < kVecCand; e++) {
+            lt[e] = _mm512_maskz_loadu_epi32(act, b->lt[e]);
+            sy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
+            sym[e] = _mm512_maskz_loadu_epi32(act, b->sym[e]);
+            top[e] = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[e]), _mm512_setzero_si512());
+        }
+        alignas(64) uint32_t w0[kVecLanes], w1[kVecLanes];
+        for (int j = 0; j < kVecLanes; j++) {
+            pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = w1[j] = 0;
+            if (act >> j & 1) { w0[j] = window_at(pw[j]); w1[j] = window_at(pw[j] + 4); }
+        }
+        win = _mm512_load_si512(w0); nxt = _mm512_load_si512(w1);
+        cnt = _mm512_set1_epi32(4);
+    }
+    __attribute__((always_inline)) inline void step(uint32_t i)
+    {
+        const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
+        const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
+        // floor(x / 60000) = ((x >> 5) * 146601551) >> 38 for every 32-bit x (checked exhaustively over x >> 5 < 2^27)
+        const __m512i magic = _mm512_set1_epi64(146601551);
+        const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
         // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
         for (;;) {
@@ -118,16 +128,17 @@ void vec_decode_block(VecBlock* b, VecOther other)
         const __mmask16 in0 = in[0], in1 = (__mmask16)(in[1] | in[2] | in[3]);
         const __mmask16 miss = act & ~(in0 | in1);
         if (__builtin_expect(miss != 0, 0)) {  // some other symbol: scalar look-up path for those lanes
+            alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
             _mm512_store_si512(tl, low); _mm512_store_si512(tr, range); _mm512_store_si512(th, help);
             unsigned m = miss;
             do {
                 const int j = __builtin_ctz(m);
                 m &= m - 1;
                 const uint32_t cj = other(b->model[j], &tl[j], &tr[j], th[j]);
-                const __mmask16 one = (__mmask16)(1u << j);
-                nlow = _mm512_mask_set1_epi32(nlow, one, (int)tl[j]);
-                nrange = _mm512_mask_set1_epi32(nrange, one, (int)tr[j]);
-                c = _mm512_mask_set1_epi32(c, one, (int)cj);
+                const __mmask16 bit = (__mmask16)(1u << j);
+                nlow = _mm512_mask_set1_epi32(nlow, bit, (int)tl[j]);
+                nrange = _mm512_mask_set1_epi32(nrange, bit, (int)tr[j]);
+                c = _mm512_mask_set1_epi32(c, bit, (int)cj);
             } while (m);
         }
         low = nlow; range = nrange;
@@ -143,12 +154,38 @@ void vec_decode_block(VecBlock* b, VecOther other)
             }
         }
     }
-    _mm512_mask_storeu_epi32(b->low, act, low);
-    _mm512_mask_storeu_epi32(b->range, act, range);
-    alignas(64) uint32_t left[kVecLanes];
-    _mm512_store_si512(left, cnt);
-    for (int j = 0; j < kVecLanes; j++)
-        if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
+    __attribute__((always_inline)) inline void fini()
+    {
+        _mm512_mask_storeu_epi32(b->low, act, low);
+        _mm512_mask_storeu_epi32(b->range, act, range);
+        alignas(64) uint32_t left[kVecLanes];
+        _mm512_store_si512(left, cnt);
+        for (int j = 0; j < kVecLanes; j++)
+            if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
+    }
+};
+
+}  // namespace
+
+void vec_decode_block(VecBlock* b, VecOther other)
+{
+    DecLanes s;
+    s.init(b, other);
+    for (uint32_t i = 0; i < kBlockSyms; i++) s.step(i);
+    s.fini();
+}
+
+// Two blocks at once, their steps interleaved: a step is a dependency chain of ~45 cycles (compare -> mask -> shift,
+// multiply-shift division, candidate products, compare -> mask -> dependent selects) that leaves most of the core's vector
+// issue slots empty; the second group's chain runs in them.
+void vec_decode_block2(VecBlock* b0, VecBlock* b1, VecOther other)
+{
+    DecLanes s0, s1;
+    s0.init(b0, other);
+    s1.init(b1, other);
+    for (uint32_t i = 0; i < kBlockSyms; i++) { s0.step(i); s1.step(i); }
+    s0.fini();
+    s1.fini();
 }
 
 void vec_decode_block_any(VecAnyBlock* b)

@@ -72,5 +72,6 @@ void vec_decode_block_any(VecAnyBlock* b);
 
 bool vec_available();  // the CPU has AVX-512 F/BW/DQ/VL and WR_NO_AVX512 is not set
 void vec_decode_block(VecBlock* b, VecOther other);
+void vec_decode_block2(VecBlock* b0, VecBlock* b1, VecOther other);  // two blocks, steps interleaved
 
 }  // namespace wrrc
