@@ -30,23 +30,28 @@ inline void transpose16x16(__m128i r[16])
 namespace {
 
 // The lanes of one VecBlock: state and one symbol step of all of them (rangecod.c:294-351 per lane).
-struct DecLanes {
+// what a step indexes by lane number: kept apart from the vector state so that the latter lives in registers
+struct DecMem {
     VecBlock* b;
     VecOther other;
+    const uint8_t* pw[kVecLanes];  // stream position the lane's current window was loaded at
+    uint8_t* d[kVecLanes];
+    __m128i rows[16];
+};
+
+struct DecLanes {
     __mmask16 act;
-    __m512i low, range, win, nxt, cnt;
+    __m512i low, range, win, win2, used;
     __m512i lt[kVecCand], sy[kVecCand], sym[kVecCand];
     __mmask16 top[kVecCand];
     // Byte feed.  The stream enters `low` as a bit string that starts 7 bits into the byte held back
     // (rangecod.c:297-299): the byte a lane shifts in at pointer q is ((q[-1] << 8 | q[0]) >> 1) & 0xff.  Every lane
-    // keeps a window of the next four such bytes (top byte first), the count of those still unused, and the
-    // window after that, already loaded: when a window runs empty the next one takes its place with one vector
-    // move, and the scalar reload of the window after it (load, byte swap, general register -> vector lane:
-    // ~25 cycles) is not needed before the lane has consumed four more bytes -- it stays off the loop's
-    // dependency chain, which the whole-register update of a just-in-time reload would sit on.
-    const uint8_t* pw[kVecLanes];  // stream position the lane's current window was loaded at
-    uint8_t* d[kVecLanes];
-    __m128i rows[16];
+    // keeps the next eight such bytes in two registers (win: the next four, top byte first; win2: the four after them)
+    // that shift as one when the lane takes a byte, and counts the bytes taken.  A step takes at most one byte per lane
+    // without looking (a second one in the same step -- a symbol of probability < 1/256 -- refills first), so looking
+    // every fourth step is enough: lanes that have taken four or more get eight fresh bytes (scalar load, byte swap,
+    // general register -> vector lane, ~25 cycles, off the loop's dependency chain).  No per-step counter test, no
+    // branch per step: the test and its mask sat on the chain of every step (tools/native/vstep_probe.cpp: 2.6 of 10 ns).
 
     static inline uint32_t window_at(const uint8_t* q)
     {
@@ -54,9 +59,11 @@ struct DecLanes {
         __builtin_memcpy(&v, q - 1, 8);
         return (uint32_t)(__builtin_bswap64(v) >> 25);
     }
-    __attribute__((always_inline)) inline void init(VecBlock* blk, VecOther oth)
+    __attribute__((always_inline)) inline void init(DecMem& mem, VecBlock* b, VecOther oth)
     {
-        b = blk; other = oth;
+        mem.b = b; mem.other = oth;
+        const uint8_t** pw = mem.pw;
+        uint8_t** d = mem.d;
         act = (__mmask16)b->active;
         // inactive lanes idle on a state that never renormalises and always "hits" candidate 0
         low = _mm512_maskz_loadu_epi32(act, b->low);
@@ -72,43 +79,57 @@ struct DecLanes {
             pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = w1[j] = 0;
             if (act >> j & 1) { w0[j] = window_at(pw[j]); w1[j] = window_at(pw[j] + 4); }
         }
-        win = _mm512_load_si512(w0); nxt = _mm512_load_si512(w1);
-        cnt = _mm512_set1_epi32(4);
+        win = _mm512_load_si512(w0); win2 = _mm512_load_si512(w1);
+        used = _mm512_setzero_si512();
     }
-    __attribute__((always_inline)) inline void step(uint32_t i)
+    // eight fresh bytes for the lanes in m
+    __attribute__((always_inline)) inline void refill(DecMem& mem, unsigned m)
     {
+        const uint8_t** pw = mem.pw;
+        alignas(64) uint32_t u[kVecLanes];
+        _mm512_store_si512(u, used);
+        used = _mm512_maskz_mov_epi32((__mmask16)~m, used);
+        m &= act;
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            pw[j] += u[j];
+            const __mmask16 bit = (__mmask16)(1u << j);
+            win = _mm512_mask_set1_epi32(win, bit, (int)window_at(pw[j]));
+            win2 = _mm512_mask_set1_epi32(win2, bit, (int)window_at(pw[j] + 4));
+        }
+    }
+    __attribute__((always_inline)) inline void step(DecMem& mem, uint32_t i)
+    {
+        VecBlock* const b = mem.b;
+        uint8_t** d = mem.d;
+        __m128i* rows = mem.rows;
         const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
-        const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
+        const __m512i one = _mm512_set1_epi32(1);
         // floor(x / 60000) = ((x >> 5) * 146601551) >> 38 for every 32-bit x (checked exhaustively over x >> 5 < 2^27)
         const __m512i magic = _mm512_set1_epi64(146601551);
-        const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
         // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in
         __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
         for (;;) {
             low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            win = _mm512_mask_slli_epi32(win, sh, win, 8);
-            cnt = _mm512_mask_sub_epi32(cnt, sh, cnt, one);
-            const __mmask16 dry = _mm512_cmpeq_epu32_mask(cnt, _mm512_setzero_si512());
-            if (dry) {
-                win = _mm512_mask_mov_epi32(win, dry, nxt);
-                cnt = _mm512_mask_mov_epi32(cnt, dry, four);
-                unsigned m = dry & act;
-                while (m) {
-                    const int j = __builtin_ctz(m);
-                    m &= m - 1;
-                    pw[j] += 4;
-                    nxt = _mm512_mask_set1_epi32(nxt, (__mmask16)(1u << j), (int)window_at(pw[j] + 4));
-                }
-            }
+            win = _mm512_mask_or_epi32(win, sh, _mm512_slli_epi32(win, 8), _mm512_srli_epi32(win2, 24));
+            win2 = _mm512_mask_slli_epi32(win2, sh, win2, 8);
+            used = _mm512_mask_add_epi32(used, sh, used, one);
             sh = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256, rare
             if (__builtin_expect(sh == 0, 1)) break;
+            refill(mem, 0xffffu);
+        }
+        if ((i & 3) == 3) {
+            const __mmask16 need = _mm512_cmpge_epu32_mask(used, _mm512_set1_epi32(4));
+            if (need) refill(mem, need);
         }
         // ---- help = range / 60000 (rangecod.c:312)
-        const __m512i n5 = _mm512_srli_epi32(range, 5);
-        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
-        const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
-        const __m512i help = _mm512_or_si512(ev, od);
+        // (even lanes: the product's bits 38.. land in the low half; odd lanes: range >> 37 of the 64-bit lane IS the odd
+        // lane's range >> 5, and the product's bits 38.. are moved to the high half by a shift of 6 and a blend)
+        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi32(range, 5), magic), 38);
+        const __m512i od = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(range, 37), magic), 6);
+        const __m512i help = _mm512_mask_mov_epi32(ev, (__mmask16)0xAAAA, od);
         // ---- which candidate: low - help*lt < width of its interval (rangecod.c:313-319, 339-351).  The intervals
         // are disjoint, so at most one test holds; an unused entry has width 0.
         __m512i a[kVecCand], w[kVecCand];
@@ -118,14 +139,14 @@ struct DecLanes {
             w[e] = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy[e]), top[e], range, a[e]);
             in[e] = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a[e]), w[e]);
         }
-        __m512i c = sym[0], sa = a[0], nrange = w[0];
-        for (int e = 1; e < kVecCand; e++) {
-            c = _mm512_mask_mov_epi32(c, in[e], sym[e]);
-            sa = _mm512_mask_mov_epi32(sa, in[e], a[e]);
-            nrange = _mm512_mask_mov_epi32(nrange, in[e], w[e]);
-        }
+        // (at most one test holds: a tree of selects, two deep, instead of three in a row)
+        static_assert(kVecCand == 4, "select tree");
+        const __mmask16 in23 = (__mmask16)(in[2] | in[3]);
+        __m512i c = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(sym[0], in[1], sym[1]), in23, _mm512_mask_mov_epi32(sym[2], in[3], sym[3]));
+        const __m512i sa = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(a[0], in[1], a[1]), in23, _mm512_mask_mov_epi32(a[2], in[3], a[3]));
+        __m512i nrange = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(w[0], in[1], w[1]), in23, _mm512_mask_mov_epi32(w[2], in[3], w[3]));
         __m512i nlow = _mm512_sub_epi32(low, sa);
-        const __mmask16 in0 = in[0], in1 = (__mmask16)(in[1] | in[2] | in[3]);
+        const __mmask16 in0 = in[0], in1 = (__mmask16)(in[1] | in23);
         const __mmask16 miss = act & ~(in0 | in1);
         if (__builtin_expect(miss != 0, 0)) {  // some other symbol: scalar look-up path for those lanes
             alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
@@ -134,7 +155,7 @@ struct DecLanes {
             do {
                 const int j = __builtin_ctz(m);
                 m &= m - 1;
-                const uint32_t cj = other(b->model[j], &tl[j], &tr[j], th[j]);
+                const uint32_t cj = mem.other(b->model[j], &tl[j], &tr[j], th[j]);
                 const __mmask16 bit = (__mmask16)(1u << j);
                 nlow = _mm512_mask_set1_epi32(nlow, bit, (int)tl[j]);
                 nrange = _mm512_mask_set1_epi32(nrange, bit, (int)tr[j]);
@@ -154,14 +175,16 @@ struct DecLanes {
             }
         }
     }
-    __attribute__((always_inline)) inline void fini()
+    __attribute__((always_inline)) inline void fini(DecMem& mem)
     {
+        VecBlock* const b = mem.b;
+        const uint8_t** pw = mem.pw;
         _mm512_mask_storeu_epi32(b->low, act, low);
         _mm512_mask_storeu_epi32(b->range, act, range);
         alignas(64) uint32_t left[kVecLanes];
-        _mm512_store_si512(left, cnt);
+        _mm512_store_si512(left, used);
         for (int j = 0; j < kVecLanes; j++)
-            if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
+            if (act >> j & 1) b->ptr[j] = pw[j] + left[j];
     }
 };
 
@@ -170,9 +193,10 @@ struct DecLanes {
 void vec_decode_block(VecBlock* b, VecOther other)
 {
     DecLanes s;
-    s.init(b, other);
-    for (uint32_t i = 0; i < kBlockSyms; i++) s.step(i);
-    s.fini();
+    DecMem m;
+    s.init(m, b, other);
+    for (uint32_t i = 0; i < kBlockSyms; i++) s.step(m, i);
+    s.fini(m);
 }
 
 // Two blocks at once, their steps interleaved: a step is a dependency chain of ~45 cycles (compare -> mask -> shift,
@@ -181,11 +205,12 @@ void vec_decode_block(VecBlock* b, VecOther other)
 void vec_decode_block2(VecBlock* b0, VecBlock* b1, VecOther other)
 {
     DecLanes s0, s1;
-    s0.init(b0, other);
-    s1.init(b1, other);
-    for (uint32_t i = 0; i < kBlockSyms; i++) { s0.step(i); s1.step(i); }
-    s0.fini();
-    s1.fini();
+    DecMem m0, m1;
+    s0.init(m0, b0, other);
+    s1.init(m1, b1, other);
+    for (uint32_t i = 0; i < kBlockSyms; i++) { s0.step(m0, i); s1.step(m1, i); }
+    s0.fini(m0);
+    s1.fini(m1);
 }
 
 void vec_decode_block_any(VecAnyBlock* b)
@@ -327,7 +352,9 @@ static void vec_encode_block_t(VecEncBlock* b)
     for (int e = 0; e < kVecCand; e++) {
         cand[e] = _mm512_mask_loadu_epi32(_mm512_set1_epi32(0x100), act, b->cand[e]);
         clt[e] = _mm512_maskz_loadu_epi32(act, b->lt[e]);
-        csy[e] = _mm512_maskz_loadu_epi32(act, b->sy[e]);
+        // (an idle lane codes its candidate 0 -- no symbol matches it, the miss test leaves idle lanes out -- with {lt 0,
+        // sy 60000} for ever: its range stays where it is, above Bottom, so no mask of the loop needs an "and active")
+        csy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
     }
     const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
     const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
@@ -462,19 +489,21 @@ static void vec_encode_block_t(VecEncBlock* b)
         // ---- renormalise (rangecod.c:182-207): lanes with range <= Bottom shift the top 9 bits out of `low`
         // (ALWAYS: the step's renormalisation runs whether or not a lane shifts -- on planes of a bit per symbol some lane
         // does in most steps, unpredictably, and the branch costs more than the dozen masked instructions)
-        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom) & act;
+        // The masks stay in mask registers: `& act` on them went through a general register and back, on the range's
+        // chain in every step.  Idle lanes never renormalise (above); the gather form's idle lanes read a zero table and do.
+        __mmask16 sh = MODE == 1 ? _mm512_mask_cmple_epu32_mask(act, range, vbottom) : _mm512_cmple_epu32_mask(range, vbottom);
         while (ALWAYS || sh) {
             if (__builtin_expect(_mm512_cmpeq_epu32_mask(cnt, four) != 0, 0)) flush_all();
             const __m512i v9 = _mm512_srli_epi32(low, 23);                 // carry bit (bit 8) + byte
             const __mmask16 isff = _mm512_mask_cmpeq_epu32_mask(sh, v9, v255);
-            __mmask16 emit = sh & ~isff;
+            __mmask16 emit = _kandn_mask16(isff, sh);
             const __m512i carrybit = _mm512_srli_epi32(v9, 8);
-            const unsigned with_ffs = _mm512_mask_test_epi32_mask(emit, ffs, ffs);
-            if (__builtin_expect(with_ffs != 0, 0)) {
-                emit_with_ffs(with_ffs, carrybit);
-                emit &= (__mmask16)~with_ffs;
-                ffs = _mm512_maskz_mov_epi32((__mmask16)~with_ffs, ffs);
-                held = _mm512_mask_and_epi32(held, (__mmask16)with_ffs, v9, v255);
+            const __mmask16 with_ffs = _mm512_mask_test_epi32_mask(emit, ffs, ffs);
+            if (__builtin_expect(!_kortestz_mask16_u8(with_ffs, with_ffs), 0)) {
+                emit_with_ffs((unsigned)with_ffs, carrybit);
+                emit = _kandn_mask16(with_ffs, emit);
+                ffs = _mm512_maskz_mov_epi32(_knot_mask16(with_ffs), ffs);
+                held = _mm512_mask_and_epi32(held, with_ffs, v9, v255);
             }
             const __m512i outb = _mm512_and_si512(_mm512_add_epi32(held, carrybit), v255);
             pend = _mm512_mask_or_epi32(pend, emit, _mm512_slli_epi32(pend, 8), outb);
@@ -483,8 +512,8 @@ static void vec_encode_block_t(VecEncBlock* b)
             ffs = _mm512_mask_add_epi32(ffs, isff, ffs, one);
             low = _mm512_mask_and_epi32(low, sh, _mm512_slli_epi32(low, 8), vtopm1);
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            sh = _mm512_cmple_epu32_mask(range, vbottom) & act;  // a second byte: symbol probability < 1/256
-            if (ALWAYS && __builtin_expect(sh == 0, 1)) break;
+            sh = MODE == 1 ? _mm512_mask_cmple_epu32_mask(act, range, vbottom) : _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256
+            if (ALWAYS && __builtin_expect(_kortestz_mask16_u8(sh, sh), 1)) break;
         }
         // ---- r = range / 60000; low += r * lt; range = r * sy, or what is left for the largest symbol (rangecod.c:217-229)
         const __m512i n5 = _mm512_srli_epi32(range, 5);
