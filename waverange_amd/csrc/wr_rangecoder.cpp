@@ -1266,7 +1266,6 @@ private:
 // group while it has room, so that up to 16 streams run as one group.
 class DualVecDecGroup {
 public:
-    static constexpr int kCap = 2 * kVecLanes;
     int count() const { return a_.count() + b_.count(); }
     bool full() const { return a_.full() && b_.full(); }
     void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag, const PlaneWindow* io = nullptr)

@@ -30,6 +30,17 @@ inline void transpose16x16(__m128i r[16])
 namespace {
 
 // The lanes of one VecBlock: state and one symbol step of all of them (rangecod.c:294-351 per lane).
+// floor(x / 60000) in every 32-bit lane = ((x >> 5) * 146601551) >> 38 (checked exhaustively over x >> 5 < 2^27).  Even
+// lanes: the product's bits 38.. land in the low half; odd lanes: x >> 37 of the 64-bit lane IS the odd lane's x >> 5, and
+// the product's bits 38.. move to the high half by a shift of 6 and a blend.
+inline __m512i div60000(__m512i x)
+{
+    const __m512i magic = _mm512_set1_epi64(146601551);
+    const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi32(x, 5), magic), 38);
+    const __m512i od = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(x, 37), magic), 6);
+    return _mm512_mask_mov_epi32(ev, (__mmask16)0xAAAA, od);
+}
+
 // what a step indexes by lane number: kept apart from the vector state so that the latter lives in registers
 struct DecMem {
     VecBlock* b;
@@ -106,30 +117,35 @@ struct DecLanes {
         __m128i* rows = mem.rows;
         const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
         const __m512i one = _mm512_set1_epi32(1);
-        // floor(x / 60000) = ((x >> 5) * 146601551) >> 38 for every 32-bit x (checked exhaustively over x >> 5 < 2^27)
-        const __m512i magic = _mm512_set1_epi64(146601551);
-        // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in
-        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
-        for (;;) {
-            low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
-            range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            win = _mm512_mask_or_epi32(win, sh, _mm512_slli_epi32(win, 8), _mm512_srli_epi32(win2, 24));
-            win2 = _mm512_mask_slli_epi32(win2, sh, win2, 8);
-            used = _mm512_mask_add_epi32(used, sh, used, one);
-            sh = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256, rare
-            if (__builtin_expect(sh == 0, 1)) break;
-            refill(mem, 0xffffu);
+        // ---- renormalise (rangecod.c:294-302): lanes with range <= Bottom shift one byte in; help = range / 60000
+        // (rangecod.c:312) of the range after it.  The quotient is worked out for the range as it is AND for the range
+        // shifted, beside the compare, and the compare's mask picks one: compare -> mask -> shift -> divide in a row was a
+        // third of the step's dependency chain.
+        const __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
+        const __m512i h_as_is = div60000(range), h_shifted = div60000(_mm512_slli_epi32(range, 8));
+        low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
+        range = _mm512_mask_slli_epi32(range, sh, range, 8);
+        win = _mm512_mask_or_epi32(win, sh, _mm512_slli_epi32(win, 8), _mm512_srli_epi32(win2, 24));
+        win2 = _mm512_mask_slli_epi32(win2, sh, win2, 8);
+        used = _mm512_mask_add_epi32(used, sh, used, one);
+        __m512i help = _mm512_mask_mov_epi32(h_as_is, sh, h_shifted);
+        __mmask16 again = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256, rare
+        if (__builtin_expect(!_kortestz_mask16_u8(again, again), 0)) {
+            do {
+                refill(mem, 0xffffu);
+                low = _mm512_mask_or_epi32(low, again, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
+                range = _mm512_mask_slli_epi32(range, again, range, 8);
+                win = _mm512_mask_or_epi32(win, again, _mm512_slli_epi32(win, 8), _mm512_srli_epi32(win2, 24));
+                win2 = _mm512_mask_slli_epi32(win2, again, win2, 8);
+                used = _mm512_mask_add_epi32(used, again, used, one);
+                again = _mm512_cmple_epu32_mask(range, vbottom);
+            } while (!_kortestz_mask16_u8(again, again));
+            help = div60000(range);
         }
         if ((i & 3) == 3) {
             const __mmask16 need = _mm512_cmpge_epu32_mask(used, _mm512_set1_epi32(4));
             if (need) refill(mem, need);
         }
-        // ---- help = range / 60000 (rangecod.c:312)
-        // (even lanes: the product's bits 38.. land in the low half; odd lanes: range >> 37 of the 64-bit lane IS the odd
-        // lane's range >> 5, and the product's bits 38.. are moved to the high half by a shift of 6 and a blend)
-        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi32(range, 5), magic), 38);
-        const __m512i od = _mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(range, 37), magic), 6);
-        const __m512i help = _mm512_mask_mov_epi32(ev, (__mmask16)0xAAAA, od);
         // ---- which candidate: low - help*lt < width of its interval (rangecod.c:313-319, 339-351).  The intervals
         // are disjoint, so at most one test holds; an unused entry has width 0.
         __m512i a[kVecCand], w[kVecCand];
@@ -356,8 +372,6 @@ static void vec_encode_block_t(VecEncBlock* b)
         // sy 60000} for ever: its range stays where it is, above Bottom, so no mask of the loop needs an "and active")
         csy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
     }
-    const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
-    const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
     const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4), v255 = _mm512_set1_epi32(0xff);
     const __m512i lane_base = _mm512_setr_epi32(0, 256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304, 2560, 2816, 3072, 3328, 3584, 3840);
     const __m512i pick_even = _mm512_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30);
@@ -492,7 +506,13 @@ static void vec_encode_block_t(VecEncBlock* b)
         // The masks stay in mask registers: `& act` on them went through a general register and back, on the range's
         // chain in every step.  Idle lanes never renormalise (above); the gather form's idle lanes read a zero table and do.
         __mmask16 sh = MODE == 1 ? _mm512_mask_cmple_epu32_mask(act, range, vbottom) : _mm512_cmple_epu32_mask(range, vbottom);
+        // r = range / 60000 of the range after renormalisation is worked out for the range as it is and for the range
+        // shifted, beside the compare; the compare's mask picks one (see DecLanes::step).  A second round: divide afterwards.
+        const __mmask16 sh0 = sh;
+        const __m512i r_as_is = div60000(range), r_shifted = div60000(_mm512_slli_epi32(range, 8));
+        int rounds = 0;
         while (ALWAYS || sh) {
+            rounds++;
             if (__builtin_expect(_mm512_cmpeq_epu32_mask(cnt, four) != 0, 0)) flush_all();
             const __m512i v9 = _mm512_srli_epi32(low, 23);                 // carry bit (bit 8) + byte
             const __mmask16 isff = _mm512_mask_cmpeq_epu32_mask(sh, v9, v255);
@@ -516,10 +536,8 @@ static void vec_encode_block_t(VecEncBlock* b)
             if (ALWAYS && __builtin_expect(_kortestz_mask16_u8(sh, sh), 1)) break;
         }
         // ---- r = range / 60000; low += r * lt; range = r * sy, or what is left for the largest symbol (rangecod.c:217-229)
-        const __m512i n5 = _mm512_srli_epi32(range, 5);
-        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
-        const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
-        const __m512i r = _mm512_or_si512(ev, od);
+        __m512i r = _mm512_mask_mov_epi32(r_as_is, sh0, r_shifted);
+        if (__builtin_expect(rounds > 1, 0)) r = div60000(range);
         const __m512i t = _mm512_mullo_epi32(r, lt);
         low = _mm512_add_epi32(low, t);
         const __mmask16 is_top = MODE == 2 ? is_top_m : _mm512_cmpeq_epu32_mask(c, top);
