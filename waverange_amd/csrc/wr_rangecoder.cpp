@@ -126,6 +126,24 @@ struct SymEntry {
     uint32_t sy;    // count of this symbol
 };
 
+// The (up to) four most frequent symbols of a block in one pass over its table, most frequent first, the smaller symbol
+// first among equals; best[e] = -1 where the block holds fewer.  Returns the number of distinct symbols.
+inline uint32_t top4_symbols(const SymEntry* tab, int best[4])
+{
+    uint32_t cnt[4] = {0, 0, 0, 0}, distinct = 0;
+    best[0] = best[1] = best[2] = best[3] = -1;
+    for (int v = 0; v < 256; v++) {
+        const uint32_t c = tab[v].sy;
+        if (!c) continue;
+        distinct++;
+        if (c <= cnt[3]) continue;
+        int e = 3;
+        while (e > 0 && c > cnt[e - 1]) { cnt[e] = cnt[e - 1]; best[e] = best[e - 1]; e--; }
+        cnt[e] = c; best[e] = v;
+    }
+    return distinct;
+}
+
 // symbols of one block; TOT > 0 selects the compile-time divisor
 // TOPSEL: the largest symbol present is frequent in this block (the two-valued trailing plane of a field
 // often is {254, 255}): "is it the largest symbol" is then a coin flip and becomes a conditional move;
@@ -443,17 +461,13 @@ public:
             }
             // the four most frequent symbols of the block; if they hold >= 99 % of every full block of this step the
             // lanes pick {lt, sy} by comparing with them, otherwise all lanes gather them from their tables
+            static_assert(kVecCand == 4, "top4_symbols");
             uint32_t cand[kVecCand], covered = 0;
+            int best[4];
+            top4_symbols(tabs_[k], best);
             for (int e = 0; e < kVecCand; e++) {
-                int best = -1;
-                for (int v = 0; v < 256; v++) {
-                    if (!tabs_[k][v].sy || (best >= 0 && tabs_[k][v].sy <= tabs_[k][best].sy)) continue;
-                    bool used = false;
-                    for (int f = 0; f < e; f++) used = used || cand[f] == (uint32_t)v;
-                    if (!used) best = v;
-                }
-                cand[e] = best < 0 ? 0x100u : (uint32_t)best;
-                if (best >= 0) covered += tabs_[k][best].sy;
+                cand[e] = best[e] < 0 ? 0x100u : (uint32_t)best[e];
+                if (best[e] >= 0) covered += tabs_[k][best[e]].sy;
             }
             if ((uint64_t)covered * 100 < (uint64_t)kBlock * 99) vb.gather = 1;
             vb.active |= 1u << k;
@@ -708,38 +722,29 @@ void finish_model_tables(BlockModel& m)
 void finish_model_stats(BlockModel& m)
 {
     m.tables_ready = false;
-    uint32_t b1 = 0, b2 = 256;
-    for (int b = 1; b < 256; b++)
-        if (m.tab[b].sy > m.tab[b1].sy) b1 = (uint32_t)b;
-    for (int b = 0; b < 256; b++)
-        if ((uint32_t)b != b1 && m.tab[b].sy && (b2 == 256 || m.tab[b].sy > m.tab[b2].sy)) b2 = (uint32_t)b;
+    int best[4];
+    const uint32_t distinct = top4_symbols(m.tab, best);
+    const uint32_t b1 = best[0] < 0 ? 0u : (uint32_t)best[0], b2 = best[1] < 0 ? 256u : (uint32_t)best[1];
     const uint32_t sy2 = b2 < 256 ? m.tab[b2].sy : 0;
     m.mps[0] = b1; m.mps_lt[0] = m.tab[b1].lt; m.mps_sy[0] = m.tab[b1].sy; m.mps_is_top[0] = b1 == m.top;
     m.mps[1] = b2 & 255; m.mps_lt[1] = sy2 ? m.tab[b2].lt : 0; m.mps_sy[1] = sy2; m.mps_is_top[1] = sy2 && b2 == m.top;
     m.mps_on = m.bs && ((uint64_t)(m.tab[b1].sy + sy2) * 100 >= (uint64_t)m.bs * WR_RC_MPS_PCT);
-    uint32_t distinct = 0;
-    for (int b = 0; b < 256; b++) {
-        if (!m.tab[b].sy) continue;
-        if (distinct < 4) { m.few_sym[distinct] = (uint32_t)b; m.few_lt[distinct] = m.tab[b].lt; m.few_sy[distinct] = m.tab[b].sy; }
-        distinct++;
-    }
     // (only where the two-symbol test above does not already cover the block: that one is shorter)
     m.few = (!m.mps_on && distinct >= 3 && distinct <= 4) ? distinct : 0;
-    for (uint32_t j = distinct; j < 4; j++) { m.few_sym[j] = m.top; m.few_lt[j] = 0xffff; m.few_sy[j] = 0; }  // help * 0xffff > low, always
+    if (distinct <= 4) {  // the symbols in ascending order (the four most frequent ones are all there are)
+        int asc[4] = {best[0], best[1], best[2], best[3]};
+        for (int i = 1; i < 4; i++)
+            for (int j = i; j > 0 && asc[j] >= 0 && (asc[j - 1] < 0 || asc[j] < asc[j - 1]); j--) { const int t = asc[j]; asc[j] = asc[j - 1]; asc[j - 1] = t; }
+        for (uint32_t j = 0; j < distinct; j++) { m.few_sym[j] = (uint32_t)asc[j]; m.few_lt[j] = m.tab[asc[j]].lt; m.few_sy[j] = m.tab[asc[j]].sy; }
+    }
+    for (uint32_t j = distinct < 4 ? distinct : 4; j < 4; j++) { m.few_sym[j] = m.top; m.few_lt[j] = 0xffff; m.few_sy[j] = 0; }  // help * 0xffff > low, always
     if (m.few) m.mps_on = true;
     // candidates of the vector loop
     uint32_t covered = 0;
     for (int e = 0; e < 4; e++) {
-        int best = -1;
-        for (int b = 0; b < 256; b++) {
-            if (!m.tab[b].sy || (best >= 0 && m.tab[b].sy <= m.tab[best].sy)) continue;
-            bool used = false;
-            for (int f = 0; f < e; f++) used = used || (m.cand_sy[f] && m.cand[f] == (uint32_t)b);
-            if (!used) best = b;
-        }
-        if (best < 0) { m.cand[e] = 0; m.cand_lt[e] = 0; m.cand_sy[e] = 0; continue; }
-        m.cand[e] = (uint32_t)best; m.cand_lt[e] = m.tab[best].lt; m.cand_sy[e] = m.tab[best].sy;
-        covered += m.tab[best].sy;
+        if (best[e] < 0) { m.cand[e] = 0; m.cand_lt[e] = 0; m.cand_sy[e] = 0; continue; }
+        m.cand[e] = (uint32_t)best[e]; m.cand_lt[e] = m.tab[best[e]].lt; m.cand_sy[e] = m.tab[best[e]].sy;
+        covered += m.tab[best[e]].sy;
     }
     m.cand_ok = m.bs && (uint64_t)covered * 100 >= (uint64_t)m.bs * WR_RC_MPS_PCT;
 }
@@ -1145,9 +1150,19 @@ public:
             const BlockModel& m = *ms_[k];
             vb.active |= 1u << k;
             vb.low[k] = d.low; vb.range[k] = d.range; vb.ptr[k] = d.in + d.pos; vb.dst[k] = dst_[k];
+            // the candidates that exist, sorted by interval start; a lane with fewer than four repeats its last one
+            // (vec_decode_block picks the last candidate whose start is at or below `low`)
+            int order[kVecCand], nc = 0;
+            for (int e = 0; e < kVecCand; e++)
+                if (m.cand_sy[e]) {
+                    int i = nc++;
+                    while (i > 0 && m.cand_lt[order[i - 1]] > m.cand_lt[e]) { order[i] = order[i - 1]; i--; }
+                    order[i] = e;
+                }
             for (int e = 0; e < kVecCand; e++) {
-                vb.lt[e][k] = m.cand_lt[e]; vb.sy[e][k] = m.cand_sy[e]; vb.sym[e][k] = m.cand[e];
-                vb.is_top[e][k] = m.cand_sy[e] && m.cand[e] == m.top;
+                const int o = order[e < nc ? e : nc - 1];
+                vb.lt[e][k] = m.cand_lt[o]; vb.sy[e][k] = m.cand_sy[o]; vb.sym[e][k] = m.cand[o];
+                vb.is_top[e][k] = m.cand[o] == m.top;
             }
             vb.model[k] = &m;
         }

@@ -76,12 +76,12 @@ struct DecLanes {
         const uint8_t** pw = mem.pw;
         uint8_t** d = mem.d;
         act = (__mmask16)b->active;
-        // inactive lanes idle on a state that never renormalises and always "hits" candidate 0
+        // inactive lanes idle on a state that never renormalises: all four candidates {lt 0, sy 60000}
         low = _mm512_maskz_loadu_epi32(act, b->low);
         range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
         for (int e = 0; e < kVecCand; e++) {
             lt[e] = _mm512_maskz_loadu_epi32(act, b->lt[e]);
-            sy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
+            sy[e] = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]);
             sym[e] = _mm512_maskz_loadu_epi32(act, b->sym[e]);
             top[e] = _mm512_mask_cmpneq_epu32_mask(act, _mm512_loadu_si512(b->is_top[e]), _mm512_setzero_si512());
         }
@@ -146,25 +146,24 @@ struct DecLanes {
             const __mmask16 need = _mm512_cmpge_epu32_mask(used, _mm512_set1_epi32(4));
             if (need) refill(mem, need);
         }
-        // ---- which candidate: low - help*lt < width of its interval (rangecod.c:313-319, 339-351).  The intervals
-        // are disjoint, so at most one test holds; an unused entry has width 0.
+        // ---- which candidate (rangecod.c:313-319, 339-351).  The lane's candidates come sorted by interval start (a lane
+        // with fewer than four repeats its last one), so the symbol is the LAST candidate whose start help * lt is at or
+        // below `low` -- three compares whose masks nest, and a two-level tree of selects -- provided `low` lies inside
+        // that candidate's interval; whether it does (else: a symbol outside the candidates, below the first one or in a
+        // gap) shows in low - start < width afterwards, off the chain that the next step waits for.
+        static_assert(kVecCand == 4, "select tree");
         __m512i a[kVecCand], w[kVecCand];
-        __mmask16 in[kVecCand];
         for (int e = 0; e < kVecCand; e++) {
             a[e] = _mm512_mullo_epi32(help, lt[e]);
             w[e] = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy[e]), top[e], range, a[e]);
-            in[e] = _mm512_cmplt_epu32_mask(_mm512_sub_epi32(low, a[e]), w[e]);
         }
-        // (at most one test holds: a tree of selects, two deep, instead of three in a row)
-        static_assert(kVecCand == 4, "select tree");
-        const __mmask16 in23 = (__mmask16)(in[2] | in[3]);
-        __m512i c = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(sym[0], in[1], sym[1]), in23, _mm512_mask_mov_epi32(sym[2], in[3], sym[3]));
-        const __m512i sa = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(a[0], in[1], a[1]), in23, _mm512_mask_mov_epi32(a[2], in[3], a[3]));
-        __m512i nrange = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(w[0], in[1], w[1]), in23, _mm512_mask_mov_epi32(w[2], in[3], w[3]));
+        const __mmask16 ge1 = _mm512_cmpge_epu32_mask(low, a[1]), ge2 = _mm512_cmpge_epu32_mask(low, a[2]), ge3 = _mm512_cmpge_epu32_mask(low, a[3]);
+        __m512i c = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(sym[0], ge1, sym[1]), ge2, _mm512_mask_mov_epi32(sym[2], ge3, sym[3]));
+        const __m512i sa = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(a[0], ge1, a[1]), ge2, _mm512_mask_mov_epi32(a[2], ge3, a[3]));
+        __m512i nrange = _mm512_mask_mov_epi32(_mm512_mask_mov_epi32(w[0], ge1, w[1]), ge2, _mm512_mask_mov_epi32(w[2], ge3, w[3]));
         __m512i nlow = _mm512_sub_epi32(low, sa);
-        const __mmask16 in0 = in[0], in1 = (__mmask16)(in[1] | in23);
-        const __mmask16 miss = act & ~(in0 | in1);
-        if (__builtin_expect(miss != 0, 0)) {  // some other symbol: scalar look-up path for those lanes
+        const __mmask16 miss = _mm512_mask_cmpge_epu32_mask(act, nlow, nrange);
+        if (__builtin_expect(!_kortestz_mask16_u8(miss, miss), 0)) {  // some other symbol: scalar look-up path for those lanes
             alignas(64) uint32_t tl[kVecLanes], tr[kVecLanes], th[kVecLanes];
             _mm512_store_si512(tl, low); _mm512_store_si512(tr, range); _mm512_store_si512(th, help);
             unsigned m = miss;

@@ -22,8 +22,9 @@ struct VecBlock {
     uint32_t low[kVecLanes], range[kVecLanes];
     const uint8_t* ptr[kVecLanes];   // next unread stream byte; ptr[-1] is the byte held back (rangecod.c:297-299)
     uint8_t* dst[kVecLanes];         // 60000 symbols each
-    // the (up to) four most probable symbols of the lane's block: interval start, width (0 = unused entry), "is
-    // the largest symbol present" (its interval is open-ended, rangecod.c:345-348)
+    // the (up to) four most probable symbols of the lane's block, SORTED BY INTERVAL START, a lane with fewer repeating
+    // its last one: interval start, width, "is the largest symbol present" (its interval is open-ended,
+    // rangecod.c:345-348)
     uint32_t lt[kVecCand][kVecLanes], sy[kVecCand][kVecLanes], is_top[kVecCand][kVecLanes], sym[kVecCand][kVecLanes];
     const void* model[kVecLanes];    // handed to `other` for a symbol outside the candidates
 };
