@@ -762,6 +762,11 @@ void finish_model(BlockModel& m)
 // idle; NS independent chains in one loop fill it.  Arithmetic per plane as in decode_symbols.
 // (The stream feeds `low` a continuous bit string that starts 7 bits into a byte:
 // held << EXTRA | next >> (8 - EXTRA), rangecod.c:297-299.)
+#ifndef WR_RC_SPEC_DIV
+#define WR_RC_SPEC_DIV 1
+#endif
+constexpr bool kSpecDiv = WR_RC_SPEC_DIV != 0;
+
 template <int NS, unsigned MPS>  // bit k of MPS: plane k's block has dominant symbols (BlockModel::mps_on)
 void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
 {
@@ -783,21 +788,28 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
             const BlockModel* const m = mod[k];
             uint32_t lw = low[k], rg = range[k];
             const uint8_t* q = p[k];
+            uint32_t help;
             {   // first renormalisation step without a branch
                 // (shifts by 0 or 8 rather than selects: compilers turn selects into branches here, and
                 // this one is badly predicted on planes of medium entropy)
                 const uint32_t sh = rg <= kBottom;
+                // range / 60000 of either outcome beside the compare (kSpecDiv): compare -> shift -> divide in a row is
+                // a tenth of the symbol's chain
+                const uint32_t h_as_is = rg / kBlock, h_shifted = kSpecDiv ? (rg << 8) / kBlock : 0;
                 const uint32_t bits = ((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff;
                 lw = (lw << (8 * sh)) | (bits & (0u - sh));
                 rg <<= 8 * sh;
                 q += sh;
+                help = kSpecDiv ? select_u32(sh, h_shifted, h_as_is) : rg / kBlock;
             }
-            while (__builtin_expect(rg <= kBottom, 0)) {
-                lw = (lw << 8) | (((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff);
-                rg <<= 8;
-                q++;
+            if (__builtin_expect(rg <= kBottom, 0)) {
+                do {
+                    lw = (lw << 8) | (((((uint32_t)q[-1] << 8) | q[0]) >> (8 - kExtra)) & 0xff);
+                    rg <<= 8;
+                    q++;
+                } while (rg <= kBottom);
+                help = rg / kBlock;
             }
-            const uint32_t help = rg / kBlock;
             uint32_t c;
             bool hit = false;
             if ((MPS >> k & 1) && m->few) {
