@@ -690,6 +690,7 @@ def main():
     thr0 = throttled_s()
     cpu0 = sum(os.times()[:2])
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
+    queue0, pwait0 = api.stat(api.STAT_POOL_QUEUE_MS), api.stat(api.STAT_PLANE_WAIT_MS)
     loops0 = api.pool_loop_stats()
     sampler = stop_sampling = None
     if args.timeline and rank == 0:
@@ -719,6 +720,9 @@ def main():
         sampler.join()
     cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
     pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
+    nfields = max(1, args.steps * batch)
+    queue_wait = (api.stat(api.STAT_POOL_QUEUE_MS) - queue0) * 1e-3 / nfields   # per field: its planes' waits for a pool worker, summed
+    plane_wait = (api.stat(api.STAT_PLANE_WAIT_MS) - pwait0) * 1e-3 / nfields   # per field: waits for device memory for its planes
     loops1 = api.pool_loop_stats()
     pool_loops = {}
     for kind in loops1:  # in-pipeline rate of every coder loop: symbols per worker-second, workers busy in it on average
@@ -837,6 +841,7 @@ def main():
         out["hbm_planes_gib"] = round(api.stat(api.STAT_DEVICE_PLANE_BYTES) / 2 ** 30, 1)  # device buffers of quantized planes (in use + idle)
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
         out["pool_loops"] = pool_loops
+        out["waits_per_field_s"] = {"planes_in_the_pool_queue_summed": round(queue_wait, 2), "device_memory_for_planes": round(plane_wait, 2)}
         out["pool_workers_idle"] = round(pool_idle, 2)  # of the pool's workers, how many were waiting for a job on average
         if throttled is not None:
             out["cpu_quota_throttled"] = round(throttled, 3)  # cgroup cpu.stat throttled time / wall time of the timed region

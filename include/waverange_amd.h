@@ -173,6 +173,9 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */
 #define WR_STAT_POOL_STREAMS_MOVED 4  /* plane streams that changed pool workers between two blocks: an idle worker takes over half
                                         of the streams of the fullest running session (WR_POOL_STEAL=0 turns that off) */
+#define WR_STAT_POOL_QUEUE_MS 5  /* milliseconds plane jobs have waited in the coder pool's queues before a worker took them, summed over jobs */
+#define WR_STAT_PLANE_WAIT_MS 6  /* milliseconds calls have waited for device memory for their quantized planes (a decoder also: for its turn
+                                    to gather them), summed over calls */
 unsigned long wr_stat(int what);
 /* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder,
  * 16-lane decoder for planes of any statistics} -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block

@@ -213,6 +213,7 @@ def test_coder_pool_same_bytes_as_oracle(oracle):
         planes.append(np.where(rs.random_sample(n) < 0.999, 7, rs.randint(0, 16, n)).astype(np.uint8))  # one dominant
         planes.append(rs.choice(np.array([3, 4, 5, 250], np.uint8), size=n))                      # four symbols
     want = [oracle.range_encode(p) for p in planes]
+    queued0 = api.stat(api.STAT_POOL_QUEUE_MS)
     try:
         for workers, streams in ((1, 2), (2, 3), (3, 4)):
             api.set_coder_pool(workers, streams)
@@ -247,6 +248,8 @@ def test_coder_pool_same_bytes_as_oracle(oracle):
         dec, got = api.range_decode_pool([enc[0], bad, enc[2][: len(enc[2]) // 2]], [p.size for p in good])
         assert got[0] == good[0].size and np.array_equal(dec[0], good[0])
         assert got[2] != good[2].size
+        # 40 planes on 1-3 workers: most of them waited in a queue before a worker had room (wr_stat: milliseconds, summed)
+        assert api.stat(api.STAT_POOL_QUEUE_MS) > queued0
     finally:
         api.set_coder_pool(0)
 

@@ -538,7 +538,10 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         c->pend_valid = false;  // whatever an earlier begin parked here is overwritten now
         // one decode at a time gathers its planes: a decoder keeps them all until its field is done, so two that each hold
         // half of theirs and wait for the other half would never finish
+        const double t_turn = now();
         std::lock_guard<std::mutex> gather(pool->planes.gather_mu);
+        const double t_got = now();
+        if (t_got - t_turn > 1e-3) g_stat[WR_STAT_PLANE_WAIT_MS] += (unsigned long)((t_got - t_turn) * 1e3);
         for (int l = 0; l < nlay; l++) if (int rc = plane_prepare(c, l, n, true)) return rc;
     }
     for (int l = 0; l < nlay; l++)

@@ -39,7 +39,7 @@ constexpr double kWavAccCoef = 1.75;
 constexpr unsigned long kSafetyBufferFactor = 1;
 constexpr int kMaxDevices = 64;
 
-extern std::atomic<unsigned long> g_stat[4];  // see wr_stat()
+extern std::atomic<unsigned long> g_stat[8];  // see wr_stat()
 std::string& last_error();            // this thread's message (wr_last_error)
 int coder_threads();                  // wr_set_threads / WR_THREADS, default one per plane
 int encoder_threads();

@@ -20,7 +20,7 @@ std::string& last_error() { return g_err; }
 std::atomic<int> g_verbose{-1};      // -1: not initialised from the environment yet
 std::atomic<int> g_threads{-1};      // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
 std::atomic<int> g_enc_threads{0};   // 0: same as g_threads (wr_set_encoder_threads)
-std::atomic<unsigned long> g_stat[4];  // see wr_stat()
+std::atomic<unsigned long> g_stat[8];  // see wr_stat()
 std::atomic<int> g_writeback{-1};    // drop-in encoding_wrap leaves the residual in fld_1d (-1: from WR_WRITEBACK_RESIDUAL, default 1)
 
 int coder_threads()
@@ -230,13 +230,14 @@ DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::
 {
     DevPlanes& dp = c->pool->planes;
     const double t0 = now();
+    bool waited = false;
     for (;;) {
         if (!dp.chunk_limit || g_stat[WR_STAT_DEVICE_PLANE_BYTES].load() + bytes <= dp.chunk_limit || [&] {
                 std::lock_guard<std::mutex> lk(dp.mu);
                 for (const DevPlanes::Buf& b : dp.idle) if (b.bytes >= bytes && b.bytes / 2 <= bytes) return true;
                 return false; }()) {
             const DevPlanes::Buf b = dp.take(bytes);
-            if (b.p) return b;
+            if (b.p) { if (waited) g_stat[WR_STAT_PLANE_WAIT_MS] += (unsigned long)((now() - t0) * 1e3); return b; }
         } else {
             // over the cap with idle buffers of other sizes lying around (another field size before): they make room
             bool any_idle;
@@ -248,6 +249,7 @@ DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::
             unlock_while_waiting->unlock();
             *unlocked = true;
         }
+        waited = true;
         std::unique_lock<std::mutex> lk(dp.mu);
         dp.cv.wait_for(lk, std::chrono::milliseconds(100));
         if (now() - t0 > 300.0) return DevPlanes::Buf();
@@ -554,7 +556,8 @@ unsigned long wr_stat(int what)
 {
     if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
     if (what == WR_STAT_POOL_STREAMS_MOVED) return wrrc::pool_streams_moved();
-    return (what >= 0 && what < 4) ? g_stat[what].load() : 0;
+    if (what == WR_STAT_POOL_QUEUE_MS) return (unsigned long)(wrrc::pool_queue_seconds() * 1e3);
+    return (what >= 0 && what < 8) ? g_stat[what].load() : 0;
 }
 void wr_set_coder_pool(int nthreads, int decoder_streams)
 {

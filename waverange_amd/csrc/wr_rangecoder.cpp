@@ -1411,8 +1411,10 @@ public:
     {
         std::lock_guard<std::mutex> lk(mu_);
         if (workers_.empty()) return false;
+        const double t_sub = now_s();
         for (int i = 0; i < count; i++) {
             jobs[i].batch = batch;
+            jobs[i].submitted = t_sub;
             // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
             const bool vec = jobs[i].kind == PlaneJob::kDecode && vec_ok_ && jobs[i].n >= 4 * (size_t)kBlock &&
                              8 * jobs[i].src_len < 2 * jobs[i].n;
@@ -1463,6 +1465,7 @@ private:
     }
 public:
     double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
+    double queue_seconds() { return queued_ns_.load() * 1e-9; }
     unsigned long streams_moved() { return moved_.load(); }
     // per loop kind (scalar encoder, scalar decoder, vector decoder, vector encoder): worker seconds spent in its block
     // steps and stream-blocks (60000 symbols each, the last block of a stream counted whole) they advanced
@@ -1472,6 +1475,7 @@ public:
     }
 private:
     std::atomic<unsigned long long> loop_ns_[kLoopKinds] = {}, loop_blocks_[kLoopKinds] = {};
+    std::atomic<unsigned long long> queued_ns_{0};  // jobs waiting in the queues for a worker, summed
     void account(int kind, double s, int nstreams)
     {
         loop_ns_[kind] += (unsigned long long)(s * 1e9);
@@ -1593,6 +1597,7 @@ private:
             while (j) {
                 Tag* t = free_tag();
                 t->job = j; t->t0 = now_s();
+                queued_ns_ += (unsigned long long)((t->t0 - j->submitted) * 1e9);
                 add(g, j, t);
                 j = g.full() ? nullptr : pop(false, kind);
             }
@@ -1714,6 +1719,7 @@ private:
 void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
+double pool_queue_seconds() { return Pool::get().queue_seconds(); }
 unsigned long pool_streams_moved() { return Pool::get().streams_moved(); }
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]) { Pool::get().loop_stats(seconds, blocks); }
 bool pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { return Pool::get().submit(jobs, count, batch); }

@@ -84,6 +84,7 @@ struct PlaneJob {
     const PlaneWindow* io = nullptr; // the symbol side (encode: src, decode: dst) comes / goes through windows instead
     size_t result = 0;             // encode: stream length; decode: symbols the stream held, (size_t)-1 if undecodable
     double seconds = 0;            // from the moment a worker took the job to its end
+    double submitted = 0;          // (pool) when the job was queued
     JobBatch* batch = nullptr;
 };
 void pool_configure(int nthreads, int dec_streams);  // nthreads = 0 stops the pool; dec_streams < 1 keeps the setting
@@ -92,6 +93,7 @@ constexpr int kLoopKinds = 5;
 // per loop kind {scalar enc, scalar dec, vector dec (dominant symbols), vector enc, vector dec (any statistics)}: worker seconds in block steps, stream-blocks advanced
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]);
 unsigned long pool_streams_moved();  // streams that changed workers between two blocks (an idle worker took over half of the fullest session)
+double pool_queue_seconds();  // time jobs have waited in the pool's queues before a worker took them, summed over jobs
 double pool_idle_seconds();  // time the workers have spent waiting for a job since the process started, summed over workers
 // The jobs must stay valid until pool_wait returns.  False (nothing queued) if the pool has no workers -- it may have
 // been stopped by another thread since the caller looked at pool_threads(): the caller then codes the planes itself.
