@@ -170,6 +170,7 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         const bool resid_upd = !s.last || c->keep_residual;
         const wrk::PlaneRef* const d_plane = plane_buf(ilay);  // device memory of this plane (the error is set if there is none)
         if (!d_plane) return WR_ERR_HIP;
+        if (!wrk::plane_ref_covers(*d_plane, n)) return fail(WR_ERR_HIP, "internal: the device buffer of plane " + std::to_string(ilay) + " has a hole");
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
         if (local) {
             wrk::LocalCutoff lc;
@@ -627,7 +628,10 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         wrk::DequantParams p;
         memset(&p, 0, sizeof p);
         p.nlay = nlay;
-        for (int l = 0; l < nlay; l++) { p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = c->ps[l].ref; }
+        for (int l = 0; l < nlay; l++) {
+            p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = c->ps[l].ref;
+            if (!wrk::plane_ref_covers(p.q[l], n)) return fail(WR_ERR_HIP, "internal: the device buffer of plane " + std::to_string(l) + " has a hole");
+        }
         double* d_fld = fld.host ? slot->field : fld.dev;
         {
             // ---- stage "kernels"

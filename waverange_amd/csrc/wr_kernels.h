@@ -35,6 +35,16 @@ struct PlaneRef {
     unsigned shift;
     __host__ __device__ uint8_t* at(size_t i) const { return chunk[i >> shift] + (i & (((size_t)1 << shift) - 1)); }
 };
+// every chunk that the bytes [0, n) of the plane fall into is there (host-side check in front of a launch: a kernel handed
+// a table with a hole in it would write through a null or stale pointer)
+inline bool plane_ref_covers(const PlaneRef& r, size_t n)
+{
+    if (!n) return true;
+    const size_t last = r.shift >= 8 * sizeof(size_t) - 1 ? 0 : (n - 1) >> r.shift;
+    if (last >= (size_t)kPlaneChunks) return false;
+    for (size_t k = 0; k <= last; k++) if (!r.chunk[k]) return false;
+    return true;
+}
 inline PlaneRef plane_ref(const uint8_t* base)  // a plane that is one array
 {
     PlaneRef r;
