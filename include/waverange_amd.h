@@ -27,6 +27,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* Everything declared here -- and nothing else -- is exported by libwaverange_amd.so (built with -fvisibility=hidden):
+ * the 24 symbols of the reference's libwaverange.so plus the wr_* functions. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ----------------------------------------------------------------------------------- */
 /* Part 1: libwaverange drop-in symbols                                                 */
@@ -176,6 +181,9 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_POOL_QUEUE_MS 5  /* milliseconds plane jobs have waited in the coder pool's queues before a worker took them, summed over jobs */
 #define WR_STAT_PLANE_WAIT_MS 6  /* milliseconds calls have waited for device memory for their quantized planes (a decoder also: for its turn
                                     to gather them), summed over calls */
+#define WR_STAT_HANDOVER_ERRORS 7  /* window requests of a host coder that were refused: the plane stream they named had moved on to another
+                                      call, they came out of order, or two coders were inside one stream (always 0 in a correct run; the
+                                      call concerned fails) */
 unsigned long wr_stat(int what);
 /* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder,
  * 16-lane decoder for planes of any statistics} -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block
@@ -326,6 +334,10 @@ int wr_range_encode_windowed(int mode, int count, const unsigned char *const *sy
 int wr_range_decode_windowed(int mode, int count, const unsigned char *const *in, const size_t *len,
                              unsigned char *const *sym, size_t n, size_t chunk, size_t *produced);
 
+/* Test hook for the plane hand-over (wr_handover.h): replays the window handle of a finished call against the plane of the
+ * next call on the same context; 0 if the request was refused and left that plane untouched. */
+int wr_test_stale_window(wr_ctx *ctx, size_t n);
+
 /* --- for callers with a batch of independent fields (the wrenc / wrdec / FluSI tools): starts the coder pool with one
  * worker per CPU this process may use (affinity mask, cgroup quota) when nfields > 1, and returns how many
  * encoding_wrap / decoding_wrap (or wr_*_host) calls on fields of field_elems elements to keep in flight at once:
@@ -339,6 +351,9 @@ int wr_autotune_batch(size_t field_elems, int nfields);
 int wr_bench_transform(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int lvl, int reps,
                        double *ms_per_transform);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -555,18 +555,24 @@ for t in ths: t.start()
 for t in ths: t.join()
 if errs: raise errs[0]
 chunk = 1 << 20
-print("plane bytes", api.stat(api.STAT_DEVICE_PLANE_BYTES), "chunks", api.stat(api.STAT_DEVICE_PLANE_BYTES) // chunk)
+print("refused", api.stat(api.STAT_HANDOVER_ERRORS), "waited_ms", api.stat(api.STAT_PLANE_WAIT_MS),
+      "plane bytes", api.stat(api.STAT_DEVICE_PLANE_BYTES), "chunks", api.stat(api.STAT_DEVICE_PLANE_BYTES) // chunk)
 '''
 
 
-@pytest.mark.parametrize("limit,pool", [(None, False), ("40", False), ("40", True), ("34", True)])
-def test_chunked_planes_drain_and_wait(tmp_path, limit, pool):
+@pytest.mark.parametrize("limit,pool,alloc_fail", [(None, False, None), ("40", False, None), ("40", True, None), ("34", True, None),
+                                                   (None, True, "30:40"), (None, False, "5:60")])
+def test_chunked_planes_drain_and_wait(tmp_path, limit, pool, alloc_fail):
     """Large planes live in chunks (the kernels index a table of them, wrk::PlaneRef); an encoder's chunks go back to the pool as
     its coder has fetched the windows they hold, and a call that finds no device memory for a plane waits for chunks to come
     back instead of failing (wr_pipeline.cpp: plane_prepare, plane_buffer_wait; WR_PLANE_LIMIT_MB caps the planes' memory).  Three callers at once, each field with 8 planes of 4 chunks (tol 1e-8): every coded byte and every
     reconstruction equal the oracle's -- with no limit, with a pool of 40 chunks (less than the 3 x 8 x 4 x 2 that three
     encodes and decodes would hold at once without draining and waiting), and with 34 (hardly more than the 32 of one
-    field's planes, which a decode holds all at once: the callers take turns)."""
+    field's planes, which a decode holds all at once: the callers take turns).
+    alloc_fail: the device allocations number first .. first+count-1 of the planes fail as if the device were full
+    (WR_TEST_PLANE_ALLOC_FAIL), so the path of a real exhaustion runs -- hipMalloc fails, the idle buffers are dropped, the
+    call hands its quantized planes to their coders and waits without its kernel-stage lock (plane_buffer_wait) -- which the
+    software cap never takes; the waits must show in WR_STAT_PLANE_WAIT_MS and no hand-over may be refused."""
     script = tmp_path / "chunks.py"
     script.write_text(CHUNK_WORKER % dict(root=ROOT))
     env = dict(os.environ, WR_PLANE_CHUNK_MB="1", WR_WINDOW_BLOCKS="2")
@@ -574,8 +580,35 @@ def test_chunked_planes_drain_and_wait(tmp_path, limit, pool):
         env["WR_PLANE_LIMIT_MB"] = limit
     if pool:
         env["POOL"] = "1"
+    if alloc_fail:
+        env["WR_TEST_PLANE_ALLOC_FAIL"] = alloc_fail
+    env["WR_FAULT_LOG"] = "1"
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "hand-over violated" not in r.stderr, r.stderr[-3000:]
+    assert int(r.stdout.split("refused")[-1].split()[0]) == 0, r.stdout
+    if alloc_fail:
+        assert int(r.stdout.split("waited_ms")[-1].split()[0]) > 0, r.stdout
     chunks = int(r.stdout.split("chunks")[-1])
     if limit:
         assert chunks <= int(limit), r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk_mb", ["1", None])
+def test_stale_window_request_is_refused(tmp_path, chunk_mb):
+    """A host coder that outlives its call must not reach the plane of the next call on the same context (wr_handover.h):
+    the window handle of a finished call is replayed against the freshly prepared plane of the next one -- chunked (1 MiB
+    chunks) and as one array.  Refused, counted in WR_STAT_HANDOVER_ERRORS, the chunk table, the ring and the window order
+    of the new plane untouched.  Before the generation tickets the callback took the live stream, started a copy into its
+    ring and marked a window as in flight."""
+    script = tmp_path / "stale.py"
+    script.write_text("import sys; sys.path.insert(0, %r)\nfrom waverange_amd import api\napi.set_verbosity(0)\n"
+                      "with api.Context(0) as c:\n    c.test_stale_window(128 * 160 * 192)\n"
+                      "print('refused', api.stat(api.STAT_HANDOVER_ERRORS))\n" % ROOT)
+    env = dict(os.environ, WR_WINDOW_BLOCKS="2")
+    if chunk_mb:
+        env["WR_PLANE_CHUNK_MB"] = chunk_mb
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "refused 1" in r.stdout and "hand-over violated" in r.stderr

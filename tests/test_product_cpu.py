@@ -23,6 +23,7 @@ def api():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "waverange_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)  # preprocessor lines
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
     return sorted(set(n for n in names if n not in ("defined",)))
 
@@ -138,6 +139,12 @@ def test_reference_export_set_is_complete(api):
         r = subprocess.check_output(["nm", "-D", "--defined-only", refso]).decode()
         ref_syms = set(line.split()[-1] for line in r.splitlines() if line.split()[-2] in "TBD")
         assert {s for s in ref_syms if not s.startswith("_")} <= have
+    # ... and nothing beyond them but the wr_* API the header declares: no C++ internals, no kernel stubs, no unprefixed
+    # helper a host program's own symbols could collide with (-fvisibility=hidden + csrc/exports.map)
+    extra = {s for s in have if s not in want and not s.startswith("wr_")}
+    assert not extra, sorted(extra)
+    undeclared = {s for s in have if s.startswith("wr_")} - set(declared_symbols())
+    assert not undeclared, sorted(undeclared)
 
 
 def test_rngcod13_primitives_and_index_map(api, oracle, golden):

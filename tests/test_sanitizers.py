@@ -39,6 +39,30 @@ def test_range_coder_under_sanitizers():
         assert "sanitizer run OK" in r.stdout
 
 
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_plane_handover_under_sanitizers(san):
+    """The coder pool (streams changing workers forced) against a mock of the pipeline's plane streams that keeps the
+    product's hand-over rules (csrc/wr_handover.h) and frees chunks the way the product does: ThreadSanitizer sees a worker
+    that touches a stream after pool_wait, AddressSanitizer a window request that reaches behind a released chunk; then
+    every violation of the rules one by one must be refused (tests/native/handover_tsan.cpp)."""
+    flags = ["-std=c++17", "-O1", "-g", "-fsanitize=" + san]
+    with tempfile.TemporaryDirectory() as d:
+        probe = os.path.join(d, "t.cpp")
+        open(probe, "w").write("int main(){return 0;}\n")
+        if subprocess.run(["g++"] + flags + [probe, "-o", os.path.join(d, "t")], capture_output=True).returncode != 0:
+            pytest.skip("g++ -fsanitize=%s not available" % san)
+        exe = os.path.join(d, "handover")
+        vec_o = os.path.join(d, "vec.o")
+        subprocess.check_call(["g++"] + flags + ["-mavx512f", "-mavx512bw", "-mavx512dq", "-mavx512vl", "-c",
+                                                 os.path.join(CSRC, "wr_rangecoder_avx512.cpp"), "-o", vec_o])
+        subprocess.check_call(["g++"] + flags + ["-I" + CSRC, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "handover_tsan.cpp"),
+                                                 os.path.join(CSRC, "wr_rangecoder.cpp"), vec_o, "-o", exe, "-lpthread"])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "hand-over run OK" in r.stdout and "refused: 0" in r.stdout
+        assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
 def test_cli_io_under_sanitizers():
     refso = os.path.join(ROOT, "oracle", "_ref", "libwaverange_ref.so")
     if not os.path.exists(refso):

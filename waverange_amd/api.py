@@ -116,6 +116,7 @@ def lib():
     L.wr_host_free.argtypes = [_vp]
     L.wr_host_register.argtypes = [_vp, C.c_size_t]
     L.wr_autotune_batch.argtypes = [C.c_size_t, C.c_int]
+    L.wr_test_stale_window.argtypes = [_vp, C.c_size_t]
     L.wr_host_unregister.argtypes = [_vp]
     L.wr_set_device_slots.argtypes = [C.c_int, C.c_int]
     L.wr_set_writeback_residual.argtypes = [C.c_int]
@@ -182,7 +183,7 @@ def set_device_slots(device, nslots):
 
 
 STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDLE_MS, STAT_POOL_STREAMS_MOVED = 0, 1, 2, 3, 4
-STAT_POOL_QUEUE_MS, STAT_PLANE_WAIT_MS = 5, 6
+STAT_POOL_QUEUE_MS, STAT_PLANE_WAIT_MS, STAT_HANDOVER_ERRORS = 5, 6, 7
 
 
 def stat(what):
@@ -594,6 +595,10 @@ class Context:
         tm = Timings()
         _check(lib().wr_decode_finish_device(self.h, buf.ptr, C.byref(tm)))
         return tm.as_dict()
+
+    def test_stale_window(self, n):
+        """Test hook: the window handle of a finished call against the plane of the next one (must be refused)."""
+        _check(lib().wr_test_stale_window(self.h, n))
 
     def transform_host(self, fld, lvl):
         nz, ny, nx = fld.shape

@@ -24,8 +24,9 @@ CLI = {"wrenc": ["cli/wrenc.cpp", "cli/gen_io.cpp"], "wrdec": ["cli/wrdec.cpp", 
        "wrenc_mssg": ["cli/mssg_enc.cpp", "cli/mssg_io.cpp"], "wrdec_mssg": ["cli/mssg_dec.cpp", "cli/mssg_io.cpp"]}
 # FluSI HDF5 front-end (libhdf5 is looked up at run time: HDF5_ROOT, the default path, /opt/conda)
 FLUSI = {"wrenc_flusi": ["cli/flusi_enc.cpp", "cli/flusi_h5.cpp"], "wrdec_flusi": ["cli/flusi_dec.cpp", "cli/flusi_h5.cpp"]}
+# -fvisibility=hidden: the library exports what include/waverange_amd.h declares and nothing else
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-          "-Wno-unused-result", "-march=x86-64-v3"]
+          "-Wno-unused-result", "-march=x86-64-v3", "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
 def _hipcc():
@@ -45,7 +46,7 @@ def _stale(target, deps):
 def _deps():
     out = [os.path.join(HERE, "..", "include", "waverange_amd.h"), os.path.abspath(__file__)]
     for root, _, files in os.walk(CSRC):
-        out += [os.path.join(root, f) for f in files if f.endswith((".hip", ".cpp", ".h"))]
+        out += [os.path.join(root, f) for f in files if f.endswith((".hip", ".cpp", ".h", ".map"))]
     return out
 
 
@@ -62,7 +63,8 @@ def build(force=False, verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lhsa-runtime64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lhsa-runtime64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib",
+                                                                             "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -171,6 +171,9 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         const wrk::PlaneRef* const d_plane = plane_buf(ilay);  // device memory of this plane (the error is set if there is none)
         if (!d_plane) return WR_ERR_HIP;
         if (!wrk::plane_ref_covers(*d_plane, n)) return fail(WR_ERR_HIP, "internal: the device buffer of plane " + std::to_string(ilay) + " has a hole");
+        // (a chunked plane is only ever indexed through its table: the direct-form kernels for unaligned pointers take one array)
+        if (d_plane->shift < 63 && (((uintptr_t)d_fld | (uintptr_t)d_plane->chunk[0]) & 15)) return fail(WR_ERR_ARG, "internal: chunked plane with an unaligned pointer");
+        launch_note(c, local ? "quant_local" : resid_upd ? "quant<1>" : "quant<0>", (int)ilay, d_fld, n, c->d_partial, *d_plane);
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
         if (local) {
             wrk::LocalCutoff lc;
@@ -186,7 +189,7 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, *d_plane, resid_upd,
                             c->d_partial, c->h_result_dev, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
-        HIPCHK(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) return fail(WR_ERR_HIP, "quantizer launch failed" + launch_describe(c));
         // the next plane's min/max is in host memory when this event fires (the reduction stores it there); what
         // after_quant enqueues runs behind it
         HIPCHK(hipEventRecord(c->ev_mm, c->stream));
@@ -363,6 +366,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         double* resid = d_fld;
         auto after_quant = [&](unsigned l) -> int {
             // block histograms of plane l on the kernel stream, behind the read-back of the next plane's min/max
+            launch_note(c, "hist", (int)l, slot->hist + l * hist_per_plane, n, nullptr, c->ps[l].ref);
             wrk::block_histograms(c->ps[l].ref, n, slot->hist + l * hist_per_plane, c->stream);
             return WR_OK;
         };
@@ -370,9 +374,9 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         StageLock cu(pool->cu_mu, std::defer_lock);
         // (the local-cutoff quantizer scatters into the plane by wavelet-space index: it wants one array)
         const bool one_array = cut.count() > 1;
-        auto plane_buf = [&](unsigned l) -> const wrk::PlaneRef* { return plane_prepare(c, (int)l, n, false, one_array, &cu) == WR_OK ? &c->ps[l].ref : nullptr; };
         // pool: plane k goes to the workers once its histograms are on the host (they set off when it completed)
         unsigned handed = 0;  // planes that have a coder (a pool job or, if the pool refused, a thread of this call)
+        unsigned ready = 0;   // planes whose histograms and first window are on their way to the host (plane_ready has run)
         auto submit_plane = [&](unsigned k) {
             if (handed >> k & 1) return;
             if (xfer_wait(&c->x_plane[k]) != WR_OK) { copy_failed[k] = 1; return; }
@@ -386,7 +390,9 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         auto plane_ready = [&](unsigned l, bool) -> int {
             // plane l and its histograms are complete on the device: the histograms go to pinned host memory, the
             // plane's first chunk sets off into its ring, and a coder thread waits for them
+            if (ready >> l & 1) return WR_OK;  // (done early, by a later plane that had to wait for device memory: before_wait)
             if (int r = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return r;
+            ready |= 1u << l;
             const Piece pc = {c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t)};
             if (int r = xfer_start(c, &c->x_plane[l], &pc, 1, kDown)) return r;
             plane_prefetch(c, (int)l);
@@ -398,19 +404,32 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             if (pooled && l > 0) submit_plane(l - 1);
             return WR_OK;
         };
+        // A plane that finds no device memory waits for chunks to come back -- and the planes this call has quantized before
+        // it are chunks that can: with the stream synchronised (plane_buffer_wait) every one of them is complete, so they
+        // all go to their coders before the wait begins instead of after the next quantizer launch.  (With fewer coder
+        // threads than planes and no pool the coders only start when the number of planes is known: nothing drains early.)
+        unsigned preparing = 0;
+        const std::function<void()> before_wait = [&]() {
+            for (unsigned k = 0; k < preparing; k++)
+                if (plane_ready(k, false) != WR_OK) return;
+            if (pooled) for (unsigned k = 0; k < preparing; k++) submit_plane(k);
+        };
+        auto plane_buf = [&](unsigned l) -> const wrk::PlaneRef* {
+            preparing = l;
+            return plane_prepare(c, (int)l, n, false, one_array, &cu, &before_wait) == WR_OK ? &c->ps[l].ref : nullptr;
+        };
         {
             // ---- stage "kernels"
-            stage_gather(pool);
+            StageGate gate(pool);
             cu.lock();
             rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, info, &local, after_quant, plane_ready, &resid);
-            (void)hipStreamSynchronize(c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess && rc == WR_OK) rc = fail(WR_ERR_HIP, "the encoder's kernel stage failed on the device" + launch_describe(c));
             if (rc == WR_OK && c->keep_residual && info->nlay && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
                 if (hipMemcpyAsync(fld.dev, resid, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
                     hipStreamSynchronize(c->stream) != hipSuccess)
                     rc = fail(WR_ERR_HIP, "residual copy failed");
             }
             cu.unlock();
-            stage_done(pool);
         }
         // ---- stage "down": the histograms were sent off as the planes completed; the residual follows them
         if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
@@ -632,17 +651,15 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             p.deps[l] = info->deps_vec[l]; p.minval[l] = info->minval_vec[l]; p.q[l] = c->ps[l].ref;
             if (!wrk::plane_ref_covers(p.q[l], n)) return fail(WR_ERR_HIP, "internal: the device buffer of plane " + std::to_string(l) + " has a hole");
         }
+        launch_note(c, "dequant", nlay - 1, fld.host ? slot->field : fld.dev, n, nullptr, p.q[nlay - 1]);
         double* d_fld = fld.host ? slot->field : fld.dev;
         {
             // ---- stage "kernels"
-            stage_gather(pool);
-            {
-                StageLock cu(pool->cu_mu);
-                rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
-                if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
-                (void)hipStreamSynchronize(c->stream);
-            }
-            stage_done(pool);
+            StageGate gate(pool);
+            StageLock cu(pool->cu_mu);
+            rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
+            if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
+            if (hipStreamSynchronize(c->stream) != hipSuccess && rc == WR_OK) rc = fail(WR_ERR_HIP, "the decoder's kernel stage failed on the device" + launch_describe(c));
         }
         if (rc) return rc;
         if (fld.host) {
@@ -762,6 +779,7 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
     return xfer_wait(&c->x_field);
 }
 
+}  // extern "C"
 namespace {
 // CPUs this process may use: its affinity mask, cut down to a cgroup CPU quota if there is one
 int usable_cpus()
@@ -801,6 +819,7 @@ size_t host_mem_available()
     return avail;
 }
 }  // namespace
+extern "C" {
 
 int wr_autotune_batch(size_t field_elems, int nfields)
 {

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -26,6 +27,7 @@
 
 #include "../../include/waverange_amd.h"
 #include "wr_dma.h"
+#include "wr_handover.h"
 #include "wr_kernels.h"
 #include "wr_rangecoder.h"
 
@@ -90,41 +92,44 @@ struct DevPlanes {
     struct Buf { uint8_t* p = nullptr; size_t bytes = 0; };
     std::mutex mu;
     std::vector<Buf> idle;
+    size_t allocated = 0;         // bytes this device's planes hold right now, in use + idle + reserved for an allocation under way (mu)
+    std::condition_variable cv;   // a buffer came back (calls waiting for device memory: plane_prepare)
+    std::mutex gather_mu;         // held by the one decode that is gathering its planes (wr_codec.cpp)
+    size_t chunk_bytes = 0;       // large planes live in chunks of this size or more (WR_PLANE_CHUNK_MB, default 32 MiB; 0: not read yet)
+    size_t chunk_limit = 0;       // WR_PLANE_LIMIT_MB: device memory the planes of all calls may take together (0: what the device gives)
+    // What the planes leave of the device's memory to everybody else (WR_PLANE_RESERVE_MB, default 2 GiB): the planes are
+    // the one consumer that allocates until the device says no, and the HIP runtime allocates too, lazily and at moments of
+    // its own (kernel-argument and signal pools, code objects of kernels used for the first time, staging for pageable
+    // copies): a device whose last megabyte went to a plane chunk leaves those allocations to fail inside the runtime,
+    // where nothing reports them (profiles/r04/NOTES.md, the round-3 fault).
+    size_t reserve_bytes = (size_t)2 << 30;
+    // Test hook (WR_TEST_PLANE_ALLOC_FAIL="first:count"): the device allocations number first .. first+count-1 of this
+    // process (0-based, counted over all devices) fail as if the device were full, so that the path "hipMalloc fails ->
+    // idle buffers are dropped -> the call waits without its kernel-stage lock" runs on a device with memory to spare.
+    static bool alloc_fails_now();
+
     void drop_idle()
     {
         std::lock_guard<std::mutex> lk(mu);
-        for (const Buf& b : idle) { wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] -= b.bytes; (void)hipFree(b.p); }
-        idle.clear();
+        drop_idle_locked();
     }
-    // smallest idle buffer that holds `bytes` without being more than twice as large, else a new one
-    Buf take(size_t bytes)
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            int best = -1;
-            for (int i = 0; i < (int)idle.size(); i++)
-                if (idle[i].bytes >= bytes && idle[i].bytes / 2 <= bytes && (best < 0 || idle[i].bytes < idle[best].bytes)) best = i;
-            if (best >= 0) { Buf b = idle[best]; idle[best] = idle.back(); idle.pop_back(); return b; }
-        }
-        Buf b;
-        void* q = nullptr;
-        if (hipMalloc(&q, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            drop_idle();  // buffers of another field size may be holding the memory
-            if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
-        }
-        if (q) { b.p = static_cast<uint8_t*>(q); b.bytes = bytes; wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] += bytes; }
-        return b;
-    }
+    // smallest idle buffer that holds `bytes` without being more than twice as large, else a new one; {nullptr, 0} if the
+    // device (or the cap) has no room right now.  The cap is checked and the bytes are booked in ONE critical section, so
+    // callers that arrive together cannot all pass the check and overshoot it.
+    Buf take(size_t bytes);
     void give(const Buf& b)
     {
         { std::lock_guard<std::mutex> lk(mu); idle.push_back(b); }
         cv.notify_all();
     }
-    std::condition_variable cv;   // a buffer came back (calls waiting for device memory: plane_prepare)
-    std::mutex gather_mu;         // held by the one decode that is gathering its planes (wr_codec.cpp)
-    size_t chunk_bytes = 0;       // large planes live in chunks of this size or more (WR_PLANE_CHUNK_MB, default 32 MiB; 0: not read yet)
-    size_t chunk_limit = 0;       // WR_PLANE_LIMIT_MB: device memory the planes of all calls may take together (0: what the device gives)
+
+private:
+    void drop_idle_locked()
+    {
+        for (const Buf& b : idle) { allocated -= b.bytes; wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] -= b.bytes; (void)hipFree(b.p); }
+        idle.clear();
+    }
+    void* device_alloc(size_t bytes);
 };
 
 struct DevPool {
@@ -183,7 +188,15 @@ struct wr_ctx {
         // wrk::PlaneRef: backing one address range with chunks that come and go -- hipMemMap / hipMemUnmap -- leaves kernels
         // reading the chunks that were there before, profiles/r03/t_vmm_probe.txt.)
         uint8_t* dev = nullptr; size_t dev_bytes = 0;   // dev: the first byte's address (non-null = the plane has storage)
-        wrk::PlaneRef ref;
+        wrk::PlaneRef ref{};
+        // Hand-over check (wr_handover.h): every plane_prepare / plane_release starts a new generation of the plane, the
+        // handle the coder gets (io.user) is a ticket for one generation, and a window request that is stale, out of
+        // order or not alone in the stream gets a scratch window instead of the ring and the chunk table
+        // (wr_pipeline.cpp: refused_window)
+        struct Ticket { PlaneStream* s = nullptr; uint64_t gen = 0; };
+        Ticket tickets[8];
+        size_t ticket_seq = 0;
+        wri::HandoverCheck ho;
         std::vector<DevPlanes::Buf> chunks;             // chunked form: chunk k, p = nullptr once it went back
         size_t released_chunks = 0;
         bool drain = false;                             // hand chunks back as the windows behind them have been fetched
@@ -199,6 +212,10 @@ struct wr_ctx {
         wrrc::PlaneWindow io;
     };
     PlaneStream ps[WR_NLAYMAX];
+    // what the context's last plane kernel (quantizer, histograms, dequantizer) was launched with: printed when the stream
+    // reports an error, and kept in a process-wide ring that WR_FAULT_LOG=1 dumps if the runtime aborts (launch_note)
+    struct LastLaunch { const char* what = nullptr; int plane = -1; const void* x = nullptr; size_t n = 0; const void* partial = nullptr; wrk::PlaneRef q{}; };
+    LastLaunch last_launch;
     // two-phase decode (wr_decode_begin / wr_decode_finish_*): the planes are decoded and wait in ps[].dev
     bool pend_valid = false;
     wr_enc_info pend_info;
@@ -313,7 +330,13 @@ using PlaneStream = wr_ctx::PlaneStream;
 void plane_release(wr_ctx* c, int l);
 // contiguous: the plane must be one array (the local-cutoff quantizer).  unlock_while_waiting: a stage lock the caller holds
 // and that must not be held while waiting for device memory that other calls' kernel stages have to free (nullptr: none)
-int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous = false, std::unique_lock<std::mutex>* unlock_while_waiting = nullptr);
+// before_wait: called once, with the context's stream synchronised and the lock still held, before the call starts to wait:
+// an encoder hands the planes it has already quantized to their coders there, so that they drain while it waits (nullptr: none)
+int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous = false, std::unique_lock<std::mutex>* unlock_while_waiting = nullptr,
+                  const std::function<void()>* before_wait = nullptr);
+// remembers what a plane kernel of the context is about to be launched with (wr_ctx::last_launch and the fault log's ring)
+void launch_note(wr_ctx* c, const char* what, int plane, const void* x, size_t n, const void* partial, const wrk::PlaneRef& q);
+std::string launch_describe(const wr_ctx* c);  // " [last plane kernel: ...]" for error messages
 void plane_prefetch(wr_ctx* c, int l);
 std::string plane_log(wr_ctx* c, int l, size_t n, const wr_enc_info* info, bool encode, size_t len);
 
@@ -350,6 +373,13 @@ struct ActiveCall {  // RAII: a codec call is inside the library
 };
 void stage_gather(DevPool* p);     // before a host call's kernel stage takes cu_mu
 void stage_done(DevPool* p);       // after it has let go of it
+struct StageGate {  // RAII pair of the two: an exception between them must not leave the gate's count raised
+    DevPool* p;
+    explicit StageGate(DevPool* pool) : p(pool) { stage_gather(p); }
+    ~StageGate() { stage_done(p); }
+    StageGate(const StageGate&) = delete;
+    StageGate& operator=(const StageGate&) = delete;
+};
 int check_dims(int nx, int ny, int nz, const void* dev_ptr);
 
 struct Sem {  // tiny counting semaphore limiting concurrent range-coder threads

@@ -484,6 +484,10 @@ void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, 
     static const bool lds_ok = !(getenv("WR_QUANT_DIRECT") && atoi(getenv("WR_QUANT_DIRECT")));
     const bool aligned = (((uintptr_t)x | (uintptr_t)q.chunk[0]) & 15) == 0;
     const bool chunked = q.shift < 63;  // (chunks are device allocations: aligned; the direct form below wants one array)
+    if (chunked && !aligned) {  // the callers check this (wr_codec.cpp); the direct form would run past the first chunk
+        fprintf(stderr, "libwaverange_amd: internal error: chunked plane with unaligned pointers (x=%p chunk0=%p)\n", (void*)x, (void*)q.chunk[0]);
+        abort();
+    }
     const size_t nchunks = ((lds_ok || chunked) && aligned) ? n / Q_CHUNK : 0;
     int g1 = 0;
     if (nchunks) {
@@ -614,7 +618,12 @@ __global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, s
 void dequant_accum(double* acc, size_t n, const DequantParams& p, hipStream_t st)
 {
     bool aligned = ((uintptr_t)acc & 15) == 0;
-    for (int l = 0; l < p.nlay; l++) aligned = aligned && ((uintptr_t)p.q[l].chunk[0] & 15) == 0;
+    bool chunked = false;
+    for (int l = 0; l < p.nlay; l++) { aligned = aligned && ((uintptr_t)p.q[l].chunk[0] & 15) == 0; chunked = chunked || p.q[l].shift < 63; }
+    if (chunked && !aligned) {  // the direct form reads chunk[0][i] for the whole plane
+        fprintf(stderr, "libwaverange_amd: internal error: chunked plane with unaligned pointers (acc=%p)\n", (void*)acc);
+        abort();
+    }
     const size_t nchunks = aligned ? n / DQ_CHUNK : 0;
     if (nchunks) {
         const size_t g = nchunks < 256 * 8 ? nchunks : 256 * 8;

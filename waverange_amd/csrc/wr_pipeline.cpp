@@ -13,6 +13,9 @@
 // caller memory goes through hipMemcpyAsync on a copy stream instead.
 #include "wr_internal.h"
 
+#include <signal.h>
+#include <unistd.h>
+
 namespace wri {
 
 thread_local std::string g_err;
@@ -82,6 +85,140 @@ hipError_t slot_ensure(Slot* s, const SlotNeed& need)
     if ((e = grow(&s->lowbuf, &s->lowbuf_elems, need.lowbuf_elems)) != hipSuccess) return e;
     if ((e = grow(&s->hist, &s->hist_elems, need.hist_elems)) != hipSuccess) return e;
     return hipSuccess;
+}
+
+}  // namespace wri
+
+// ---- device memory of the quantized planes ---------------------------------------------------------------------------
+bool DevPlanes::alloc_fails_now()
+{
+    static const struct Hook {
+        long first = -1, count = 0;
+        Hook()
+        {
+            if (const char* e = getenv("WR_TEST_PLANE_ALLOC_FAIL")) {
+                char* end = nullptr;
+                first = strtol(e, &end, 10);
+                count = (end && *end == ':') ? strtol(end + 1, nullptr, 10) : 1;
+                if (first < 0 || count < 1) first = -1;
+            }
+        }
+    } hook;
+    static std::atomic<long> seq{0};
+    if (hook.first < 0) return false;
+    const long k = seq++;
+    return k >= hook.first && k < hook.first + hook.count;
+}
+
+void* DevPlanes::device_alloc(size_t bytes)
+{
+    if (alloc_fails_now()) return nullptr;
+    if (reserve_bytes) {  // (the calling thread has the context's device bound: ctx_bind)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
+        else if (free_b < bytes + reserve_bytes) return nullptr;
+    }
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return q;
+}
+
+DevPlanes::Buf DevPlanes::take(size_t bytes)
+{
+    for (int attempt = 0; attempt < 2; attempt++) {
+        bool any_idle = false, booked = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); i++)
+                if (idle[i].bytes >= bytes && idle[i].bytes / 2 <= bytes && (best < 0 || idle[i].bytes < idle[best].bytes)) best = i;
+            if (best >= 0) { Buf b = idle[best]; idle[best] = idle.back(); idle.pop_back(); return b; }
+            any_idle = !idle.empty();
+            if (!chunk_limit || allocated + bytes <= chunk_limit) {
+                allocated += bytes;
+                wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] += bytes;
+                booked = true;
+            }
+        }
+        if (booked) {
+            if (void* q = device_alloc(bytes)) { Buf b; b.p = static_cast<uint8_t*>(q); b.bytes = bytes; return b; }
+            std::lock_guard<std::mutex> lk(mu);
+            allocated -= bytes;
+            wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] -= bytes;
+            any_idle = !idle.empty();
+        }
+        // no room: idle buffers of another size (another field size before) may be holding it
+        if (!any_idle) break;
+        drop_idle();
+    }
+    return Buf();
+}
+
+namespace wri {
+
+// ---- what the plane kernels were launched with -----------------------------------------------------------------------
+// A GPU memory fault ends the process inside the runtime (the queue's error callback calls abort()), so no error path of
+// this library ever sees it.  Every launch of a kernel that works through a plane's chunk table is therefore noted in a
+// process-wide ring beforehand; with WR_FAULT_LOG=1 a SIGABRT handler writes the ring to stderr before the process dies, so
+// that a fault can be attributed to a launch, its pointers and the chunk table it was given.
+namespace {
+struct LaunchRecord {
+    double t; const void* ctx; int device; char what[12]; int plane; const void* x; size_t n; const void* partial;
+    unsigned shift; const void* chunk[wrk::kPlaneChunks];
+};
+constexpr unsigned kLaunchRing = 128;
+LaunchRecord g_launches[kLaunchRing];
+std::atomic<unsigned> g_launch_seq{0};
+
+void fault_log_dump(int)
+{
+    char line[640];
+    const unsigned end = g_launch_seq.load();
+    const unsigned begin = end > kLaunchRing ? end - kLaunchRing : 0;
+    int len = snprintf(line, sizeof line, "libwaverange_amd: abort -- the last %u plane-kernel launches (oldest first), planes hold %lu bytes of device memory\n",
+                       end - begin, (unsigned long)g_stat[WR_STAT_DEVICE_PLANE_BYTES].load());
+    (void)!write(2, line, (size_t)len);
+    for (unsigned k = begin; k < end; k++) {
+        const LaunchRecord& r = g_launches[k % kLaunchRing];
+        len = snprintf(line, sizeof line, "  #%u t=%.6f ctx=%p dev=%d %s plane=%d x=%p n=%zu partial=%p shift=%u chunks:", k, r.t, r.ctx, r.device, r.what,
+                       r.plane, r.x, r.n, r.partial, r.shift);
+        const size_t nch = r.shift >= 63 ? 1 : ((r.n ? r.n - 1 : 0) >> r.shift) + 1;
+        for (size_t i = 0; i < nch && i < (size_t)wrk::kPlaneChunks && len < (int)sizeof line - 24; i++)
+            len += snprintf(line + len, sizeof line - (size_t)len, " %p", r.chunk[i]);
+        if (len < (int)sizeof line - 1) line[len++] = '\n';
+        (void)!write(2, line, (size_t)len);
+    }
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+}
+
+const bool g_fault_log_installed = []() {
+    const char* e = getenv("WR_FAULT_LOG");
+    if (!(e && atoi(e))) return false;
+    signal(SIGABRT, fault_log_dump);
+    return true;
+}();
+}  // namespace
+
+void launch_note(wr_ctx* c, const char* what, int plane, const void* x, size_t n, const void* partial, const wrk::PlaneRef& q)
+{
+    wr_ctx::LastLaunch& l = c->last_launch;
+    l.what = what; l.plane = plane; l.x = x; l.n = n; l.partial = partial; l.q = q;
+    LaunchRecord& r = g_launches[g_launch_seq.fetch_add(1) % kLaunchRing];
+    r.t = now(); r.ctx = c; r.device = c->device; r.plane = plane; r.x = x; r.n = n; r.partial = partial; r.shift = q.shift;
+    snprintf(r.what, sizeof r.what, "%s", what);
+    for (int k = 0; k < wrk::kPlaneChunks; k++) r.chunk[k] = q.chunk[k];
+}
+
+std::string launch_describe(const wr_ctx* c)
+{
+    const wr_ctx::LastLaunch& l = c->last_launch;
+    if (!l.what) return std::string();
+    char b[512];
+    int len = snprintf(b, sizeof b, " [last plane kernel: %s plane=%d x=%p n=%zu partial=%p shift=%u chunks", l.what, l.plane, l.x, l.n, l.partial, l.q.shift);
+    const size_t nch = l.q.shift >= 63 ? 1 : ((l.n ? l.n - 1 : 0) >> l.q.shift) + 1;
+    for (size_t i = 0; i < nch && i < (size_t)wrk::kPlaneChunks && len < (int)sizeof b - 24; i++) len += snprintf(b + len, sizeof b - (size_t)len, " %p", l.q.chunk[i]);
+    return std::string(b, (size_t)len) + "]";
 }
 
 int ensure_enc_buf(wr_ctx* c, int l, size_t bytes)
@@ -191,6 +328,8 @@ void plane_release(wr_ctx* c, int l)
     }
     s.dev = nullptr; s.dev_bytes = 0;
     s.released_chunks = 0; s.drain = false;
+    s.ho.retire();  // window tickets cut for this plane are void from here on
+    s.io.user = nullptr; s.io.window = nullptr;
 }
 
 namespace {
@@ -221,33 +360,28 @@ void planes_configure(DevPlanes& dp)
     dp.chunk_bytes = c;
     if (const char* e = getenv("WR_PLANE_CHUNKS")) if (!atoi(e)) dp.chunk_bytes = ~(size_t)0 >> 1;  // WR_PLANE_CHUNKS=0: every plane one buffer
     if (const char* e = getenv("WR_PLANE_LIMIT_MB")) { const long v = atol(e); if (v >= 1) dp.chunk_limit = (size_t)v << 20; }
+    if (const char* e = getenv("WR_PLANE_RESERVE_MB")) { const long v = atol(e); if (v >= 0) dp.reserve_bytes = (size_t)v << 20; }
 }
 
 // A plane buffer of `bytes`; if the device (or WR_PLANE_LIMIT_MB) has no room, waits for one to come back -- other calls'
 // encoders return their chunks as their coders advance, decoders when their field is done -- without the caller's kernel-stage
 // lock, which those other calls may need to get there.
-DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::mutex>* unlock_while_waiting, bool* unlocked)
+DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::mutex>* unlock_while_waiting, bool* unlocked,
+                                 const std::function<void()>* before_wait)
 {
     DevPlanes& dp = c->pool->planes;
     const double t0 = now();
     bool waited = false;
     for (;;) {
-        if (!dp.chunk_limit || g_stat[WR_STAT_DEVICE_PLANE_BYTES].load() + bytes <= dp.chunk_limit || [&] {
-                std::lock_guard<std::mutex> lk(dp.mu);
-                for (const DevPlanes::Buf& b : dp.idle) if (b.bytes >= bytes && b.bytes / 2 <= bytes) return true;
-                return false; }()) {
-            const DevPlanes::Buf b = dp.take(bytes);
-            if (b.p) { if (waited) g_stat[WR_STAT_PLANE_WAIT_MS] += (unsigned long)((now() - t0) * 1e3); return b; }
-        } else {
-            // over the cap with idle buffers of other sizes lying around (another field size before): they make room
-            bool any_idle;
-            { std::lock_guard<std::mutex> lk(dp.mu); any_idle = !dp.idle.empty(); }
-            if (any_idle) { dp.drop_idle(); continue; }
-        }
-        if (unlock_while_waiting && !*unlocked) {
-            (void)hipStreamSynchronize(c->stream);  // what this call has queued must not straddle the gap in its kernel stage
-            unlock_while_waiting->unlock();
-            *unlocked = true;
+        const DevPlanes::Buf b = dp.take(bytes);  // (the cap is checked and booked there, idle buffers of other sizes make room)
+        if (b.p) { if (waited) g_stat[WR_STAT_PLANE_WAIT_MS] += (unsigned long)((now() - t0) * 1e3); return b; }
+        if (!waited) {
+            // what this call has queued must not straddle the gap in its kernel stage
+            if (unlock_while_waiting || before_wait) (void)hipStreamSynchronize(c->stream);
+            // the planes this call has quantized so far go to their coders now: they drain while it waits -- they may be
+            // exactly what it is waiting for
+            if (before_wait && *before_wait) (*before_wait)();
+            if (unlock_while_waiting && !*unlocked) { unlock_while_waiting->unlock(); *unlocked = true; }
         }
         waited = true;
         std::unique_lock<std::mutex> lk(dp.mu);
@@ -258,11 +392,42 @@ DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::
 
 }  // namespace
 
+namespace {
+
+// A window callback that must not be served -- its ticket is of an earlier generation of the plane (a coder that outlived
+// its call), it is out of order, it comes after the stream's end, or another callback is inside the same stream -- gets
+// this scratch window instead of the plane's ring and chunk table: the coder it belongs to runs on harmlessly (its bytes
+// are discarded with the call's error), the plane of the call that owns the stream now is not touched.
+uint8_t* refused_window(PlaneStream* s, const char* who, const char* why, size_t first, size_t* count)
+{
+    static std::mutex mu;
+    static uint8_t* scratch = nullptr;
+    g_stat[WR_STAT_HANDOVER_ERRORS]++;
+    if (s) s->err = 1;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!scratch) scratch = static_cast<uint8_t*>(calloc(1, kChunkBytes));
+        static int reported = 0;
+        if (reported++ < 8)
+            fprintf(stderr, "libwaverange_amd: plane hand-over violated in %s: %s (first=%zu count=%zu plane stream %p) -- window refused\n", who, why,
+                    first, *count, (void*)s);
+    }
+    if (*count > kChunkSyms) *count = kChunkSyms;
+    return *count ? scratch : nullptr;
+}
+
+}  // namespace
+
 // Encoder side: the symbols [first, first + count) of the plane, fetched into the ring; the following chunk is
 // started into the buffer the coder has just left, so that it arrives while this one is being coded.
 uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
 {
-    PlaneStream& s = *static_cast<PlaneStream*>(user);
+    const PlaneStream::Ticket* const tk = static_cast<const PlaneStream::Ticket*>(user);
+    PlaneStream& s = *tk->s;
+    if (!s.ho.current(tk->gen)) return refused_window(nullptr, "plane_window_encode", "the ticket is of an earlier generation of this plane", first, count);
+    HandoverGuard guard(s.ho);
+    if (!guard.alone) return refused_window(&s, "plane_window_encode", "two coders inside one plane stream", first, count);
+    if (const char* why = s.ho.check_encode(first, *count)) return refused_window(&s, "plane_window_encode", why, first, count);
     wr_ctx* const c = s.c;
     (void)hipSetDevice(c->device);  // coder threads: the pageable-copy fallback of xfer_start needs the device bound
     const size_t want = *count < kChunkSyms ? *count : kChunkSyms;
@@ -291,6 +456,7 @@ uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
         if (xfer_start(c, &s.x[b ^ 1], pc, np, kDown) == WR_OK) { s.ahead = true; s.ahead_first = next; }
         else s.err = 1;
     }
+    s.ho.served(first, want, true);
     *count = want;
     return s.buf[b];
 }
@@ -299,7 +465,12 @@ uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
 // *count == 0 ends the stream: both uploads are waited for.
 uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
 {
-    PlaneStream& s = *static_cast<PlaneStream*>(user);
+    const PlaneStream::Ticket* const tk = static_cast<const PlaneStream::Ticket*>(user);
+    PlaneStream& s = *tk->s;
+    if (!s.ho.current(tk->gen)) return refused_window(nullptr, "plane_window_decode", "the ticket is of an earlier generation of this plane", first, count);
+    HandoverGuard guard(s.ho);
+    if (!guard.alone) return refused_window(&s, "plane_window_decode", "two coders inside one plane stream", first, count);
+    if (const char* why = s.ho.check_decode(first, *count)) return refused_window(&s, "plane_window_decode", why, first, count);
     wr_ctx* const c = s.c;
     (void)hipSetDevice(c->device);
     if (s.win_count) {
@@ -310,6 +481,7 @@ uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
     }
     if (*count == 0) {
         for (int b = 0; b < 2; b++) { if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1; s.copy_ms += s.x[b].ms; s.x[b].ms = 0; }
+        s.ho.end();
         return nullptr;
     }
     const int b = s.cur ^ 1;
@@ -318,13 +490,15 @@ uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
     s.cur = b;
     s.win_first = first;
     s.win_count = *count < kChunkSyms ? *count : kChunkSyms;
+    s.ho.served(first, s.win_count, false);
     *count = s.win_count;
     return s.buf[b];
 }
 
 // plane l of n symbols for this call: a device buffer (kept if the context holds one that fits: a finish after a
 // begin), the ring, and the window callbacks of the direction
-int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous, std::unique_lock<std::mutex>* unlock_while_waiting)
+int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous, std::unique_lock<std::mutex>* unlock_while_waiting,
+                  const std::function<void()>* before_wait)
 {
     PlaneStream& s = c->ps[l];
     const size_t bytes = wr_plane_pitch(n);
@@ -348,7 +522,7 @@ int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous, std:
             for (int k = 0; k < wrk::kPlaneChunks; k++) s.ref.chunk[k] = nullptr;
             s.chunks.assign(nch, DevPlanes::Buf());
             for (size_t k = 0; k < nch; k++) {
-                const DevPlanes::Buf b = plane_buffer_wait(c, cb, unlock_while_waiting, &unlocked);
+                const DevPlanes::Buf b = plane_buffer_wait(c, cb, unlock_while_waiting, &unlocked, before_wait);
                 if (!b.p) {
                     for (DevPlanes::Buf& q : s.chunks) if (q.p) dp.give(q);
                     s.chunks.clear();
@@ -359,7 +533,7 @@ int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous, std:
             }
             s.dev = s.chunks[0].p; s.dev_bytes = nch * cb;
         } else {
-            const DevPlanes::Buf b = plane_buffer_wait(c, bytes, unlock_while_waiting, &unlocked);
+            const DevPlanes::Buf b = plane_buffer_wait(c, bytes, unlock_while_waiting, &unlocked, before_wait);
             if (!b.p) { if (unlocked) unlock_while_waiting->lock(); return fail(WR_ERR_HIP, no_room); }
             s.dev = b.p; s.dev_bytes = b.bytes;
             s.ref = wrk::plane_ref(b.p);
@@ -381,8 +555,12 @@ int plane_prepare(wr_ctx* c, int l, size_t n, bool decode, bool contiguous, std:
     s.c = c; s.n = n;
     s.cur = 1; s.win_first = s.win_count = 0; s.ahead = false; s.ahead_first = 0; s.err = 0; s.copy_ms = 0;
     s.x[0].ms = s.x[1].ms = 0;
+    // a new generation of the plane: the coder's handle is a ticket for exactly this one
+    const uint64_t g = s.ho.begin(n);
+    PlaneStream::Ticket& tk = s.tickets[s.ticket_seq++ % 8];  // (a coder would have to be eight calls late to meet its ticket re-cut)
+    tk.s = &s; tk.gen = g;
     s.io.window = decode ? plane_window_decode : plane_window_encode;
-    s.io.user = &s;
+    s.io.user = &tk;
     return WR_OK;
 }
 
@@ -846,5 +1024,34 @@ int wr_dev_synth_field(wr_ctx* c, double* d_out, int nx, int ny, int nz, unsigne
 }
 
 size_t wr_plane_pitch(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// Test hook: a host coder that outlives its call.  Plane 0 of the context is prepared as an encoder's plane of n symbols
+// (call A), released (A is over) and prepared again (call B); then A's window handle asks for its first window, as a pool
+// worker that was still holding A's stream would.  The request must be refused: B's chunk table, ring and window order stay
+// as plane_prepare left them and WR_STAT_HANDOVER_ERRORS goes up by one.
+int wr_test_stale_window(wr_ctx* c, size_t n)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (!n) return fail(WR_ERR_ARG, "empty plane");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (int rc = plane_prepare(c, 0, n, false)) return rc;
+    PlaneStream& s = c->ps[0];
+    const wrrc::PlaneWindow late = s.io;
+    plane_release(c, 0);
+    if (int rc = plane_prepare(c, 0, n, false)) return rc;
+    const wrk::PlaneRef before = s.ref;
+    const unsigned long refused0 = g_stat[WR_STAT_HANDOVER_ERRORS].load();
+    size_t count = n;
+    uint8_t* const w = late.window(late.user, 0, &count);
+    (void)xfer_wait(&s.x[0]); (void)xfer_wait(&s.x[1]);
+    const bool intact = memcmp(&before, &s.ref, sizeof before) == 0 && s.ho.next_first == 0 && !s.ho.ended && !s.ahead && !s.err &&
+                        w != s.buf[0] && w != s.buf[1];
+    const unsigned long refused = g_stat[WR_STAT_HANDOVER_ERRORS].load() - refused0;
+    s.ahead = false;
+    plane_release(c, 0);
+    if (!intact) return fail(WR_ERR_HIP, "a window request with the handle of an earlier call reached the plane of the present one");
+    if (refused != 1) return fail(WR_ERR_HIP, "the stale window request was not counted as refused");
+    return WR_OK;
+}
 
 }  // extern "C"
