@@ -424,6 +424,9 @@ def main():
     ap.add_argument("--pool", type=int, default=-1, help="coder-pool worker threads shared by all fields in flight (-1: one per CPU of this rank; 0: no pool, "
                     "every call runs its own --threads coder threads)")
     ap.add_argument("--dec-streams", type=int, default=4, help="plane streams a pool worker's decoder loop interleaves (1..4)")
+    ap.add_argument("--secondary-steps", type=int, default=2, help="steps of the secondary pass at --secondary-tol after the timed region (N = 1 only; 0: none)")
+    ap.add_argument("--secondary-tol", type=float, default=1e-16, help="BASELINE configs[4]'s near-lossless tolerance: 8 planes per field, mostly noise")
+    ap.add_argument("--secondary-lanes", type=int, default=8, help="fields in flight in the secondary pass (each holds up to 2 x 6 GB of coded bytes at 1024^3)")
     args = ap.parse_args()
     tols = [float(t) for t in args.tols.split(",")]
     n = args.size
@@ -456,7 +459,13 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py: no GPU visible (libwaverange_amd has no CPU fallback)")
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
-    if world > 1:
+    # Under a launcher (RANK / WORLD_SIZE / MASTER_* in the environment: torch.distributed.run, or launch_ranks above) the
+    # process group is set up whatever the number of ranks -- with WORLD_SIZE=1 too, so that the one-GPU run the driver
+    # launches through torch.distributed.run takes the same RCCL barrier and max-reduction as the 8-GPU one.
+    launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    if world > 1 and not launched:
+        raise SystemExit("bench.py: WORLD_SIZE=%d without RANK / MASTER_ADDR / MASTER_PORT" % world)
+    if launched:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
@@ -464,6 +473,7 @@ def main():
         else:
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    barrier_kind = "none (one process, no launcher)" if dist is None else "rccl" if backend == "nccl" else backend
     import numpy as np
     from waverange_amd import api
     api.set_verbosity(0)
@@ -493,6 +503,21 @@ def main():
                             pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev, nslots=args.slots or 3,
                             planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
     limits["cpu_affinity_share"] = share
+
+    def cpu_ranges(cpus):
+        out, cpus = [], sorted(cpus)
+        for c in cpus:
+            if out and c == out[-1][1] + 1:
+                out[-1][1] = c
+            else:
+                out.append([c, c])
+        return ",".join("%d" % a if a == b else "%d-%d" % (a, b) for a, b in out)
+
+    limits["cpus"] = cpu_ranges(os.sched_getaffinity(0))
+    rank_sizing = None
+    if dist is not None and world > 1:  # what every rank found for itself: disjoint CPU shares, equal lanes (weak scaling)
+        rank_sizing = [None] * world
+        dist.all_gather_object(rank_sizing, dict(limits, rank=rank, device=dev_index))
     trim_host = bool(limits.get("host_pages_of_consumed_streams_dropped")) or args.trim_host
     pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
     if pool_workers:
@@ -573,9 +598,10 @@ def main():
     lock = threading.Lock()
     errors = []
 
-    def run_steps(nsteps, record):
+    def run_steps(nsteps, record, tols=tols, lanes=lanes, batch=batch, trim_host=trim_host):
         """nsteps steps = nsteps x batch fields (field i at tolerance tols[i % len(tols)]), pulled from one queue by the
-        lanes; returns when all of them have been encoded AND decoded."""
+        lanes; returns when all of them have been encoded AND decoded.  (The secondary pass runs other tolerances on
+        fewer lanes: the keyword arguments.)"""
         total = nsteps * batch
         nxt = [0]
 
@@ -778,12 +804,13 @@ def main():
                                       else "parity-size run"),
                        "boundary": "host buffers (pinned), wr_encode_host / wr_decode_begin + wr_decode_finish_host (%d output fields shared by the lanes)" % out_pool.qsize() if host_mode else "device buffers, wr_encode_device / wr_decode_device",
                        "field_shards": world,
+                       "barrier": barrier_kind,
                        "multi_gpu": ("weak scaling: every rank round-trips its own stream of %d^3 fields (seed 12345 + rank) on its own GPU and its share of the "
                                      "host cores, no data-path collective%s" % (n, "" if n == 512 else "; BASELINE configs[3] (NF = 8 x 512^3, one per GPU) is this with --size 512"))
                        if world > 1 else None,
                        "range_coder": ({"pool_workers": pool_workers, "decoder_streams_per_loop": args.dec_streams, "encoder_streams_per_loop": 3} if pool_workers
                                        else {"threads_per_call": {"encode": args.enc_threads or args.threads, "decode": args.threads}}),
-                       "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": batch, "sizing": limits,
+                       "concurrent_jobs_per_gpu": len(lanes), "fields_per_step_per_gpu": batch, "sizing": limits, "sizing_of_every_rank": rank_sizing,
                        "pipeline": "a step is a batch of %d fields (%d per tolerance); the %d lanes (encoder + decoder context each) pull fields from the run's queue, "
                                    "so steps overlap: a lane encodes its next field while it decodes the previous one" % (batch, batch // len(tols), len(lanes)),
                        "planes": {("%g" % t): stats[t] for t in tols}},
@@ -845,6 +872,35 @@ def main():
         out["pool_workers_idle"] = round(pool_idle, 2)  # of the pool's workers, how many were waiting for a job on average
         if throttled is not None:
             out["cpu_quota_throttled"] = round(throttled, 3)  # cgroup cpu.stat throttled time / wall time of the timed region
+        if world == 1 and args.secondary_steps > 0 and host_mode and pool_workers:
+            # BASELINE configs[4]'s tolerance on the same pipeline, outside the timed region: a bounded sample (few lanes, few
+            # steps: mostly fill and drain) so that the command stays within minutes; `bench.py --tols 1e-16` is the full run
+            try:
+                for ln in lanes:   # the pages of the main run's coded streams go back first: a 1e-16 stream is 6 GB at 1024^3
+                    for buf in ln["data"]:
+                        drop_pages(buf, cap)
+                avail = None
+                with open("/proc/meminfo") as fh:
+                    avail = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]
+                for path in ("/sys/fs/cgroup/memory.max",):
+                    m, cur = _cgroup_number(path), _cgroup_number("/sys/fs/cgroup/memory.current")
+                    if m and cur and m[0] != "max":
+                        avail = min(avail, int(m[0]) - int(cur[0]))
+                nl = max(1, min(args.secondary_lanes, len(lanes), int(0.5 * avail // (2 * 0.75 * nbytes_field))))
+                sb = nl  # one field per lane and step
+                t2 = time.perf_counter()
+                stats[args.secondary_tol] = {}
+                run_steps(args.secondary_steps, False, tols=[args.secondary_tol], lanes=lanes[:nl], batch=sb, trim_host=True)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t2
+                out["secondary"] = {"tol_%g" % args.secondary_tol: {
+                    "value": round(args.secondary_steps * sb * field_mb / dt2, 2), "unit": "MB/s", "lanes": nl, "steps": args.secondary_steps,
+                    "fields": args.secondary_steps * sb, "seconds": round(dt2, 1),
+                    "note": "BASELINE configs[4]'s tolerance (8 planes per field, six of them noise) through the same pipeline after the timed region; "
+                            "a bounded sample -- %d fields on %d lanes, fill and drain included -- not the steady-state rate (`bench.py --tols %g`)"
+                            % (args.secondary_steps * sb, nl, args.secondary_tol)}}
+            except Exception as exc:  # noqa: BLE001
+                out["secondary"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             # one field alone on the idle machine, a coder thread per plane: the latency a single
             # encoding_wrap / decoding_wrap caller sees (outside the timed region)

@@ -294,6 +294,11 @@ int wr_transform_host(wr_ctx *ctx, double *h_fld, int nx, int ny, int nz, int lv
 
 /* --- host range coder alone (one plane stream), rows a6/a7/a10 of SURVEY.md 8a */
 size_t wr_range_encode_bound(size_t n);
+/* the same for a plane whose byte histograms per 60000-symbol block are known (unsigned short[256] per block, n/60000+1
+ * blocks): block entropies + headers + the coder's worst-case rounding loss (0.0104 bit per symbol), a rigorous bound
+ * within ~0.2 % of the stream's length.  wr_encode_* use it to code the planes of a field side by side straight into
+ * data_enc (the reference codes each plane into a buffer of its own and copies, wrappers.cpp:412-427). */
+size_t wr_range_encode_bound_hist(const unsigned short *hists, size_t n);
 size_t wr_range_encode(const unsigned char *sym, size_t n, unsigned char *out);
 size_t wr_range_decode(const unsigned char *in, size_t len, unsigned char *sym, size_t n);
 /* `count` planes of n symbols each coded on the calling thread, their symbol loops interleaved

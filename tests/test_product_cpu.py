@@ -501,3 +501,28 @@ def test_two_decoder_groups_per_session_same_symbols():
     out = subprocess.run([sys.executable, "-c", DUAL_GROUPS % ROOT], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] in ("ok", "no AVX-512")
+
+
+def test_stream_length_bound_from_histograms(api):
+    """wr_range_encode_bound_hist: what lets the planes of a field be coded side by side straight into data_enc.  It must
+    never be below the stream's length -- whatever the statistics: noise, few symbols, a single value, skewed blocks that put
+    the coder's rounding loss at its worst, a plane ending on a block boundary (extra empty block) -- and it must be tight
+    (the gaps between the planes are what is moved afterwards)."""
+    rs = np.random.RandomState(7)
+    planes = []
+    for n in (1, 59999, 60000, 60001, 180000, 60000 * 17 + 4321):
+        planes.append(rs.randint(0, 256, size=n).astype(np.uint8))                                  # noise
+        planes.append(rs.choice(np.array([127, 128], np.uint8), size=n, p=[0.8, 0.2]))               # two symbols
+        planes.append(np.full(n, 200, np.uint8))                                                     # one value: 0 bits per symbol
+        planes.append((rs.standard_normal(n) * 3 + 128).clip(0, 255).astype(np.uint8))               # a quantizer's middle plane
+        p = np.full(n, 7, np.uint8); p[rs.randint(0, n, size=max(1, n // 30000))] = 255               # counts of 1-2 per block: r * sy << range * sy / tot
+        planes.append(p)
+        planes.append((np.arange(n) % 251).astype(np.uint8))                                         # 251 equally likely symbols
+    for p in planes:
+        real = api.range_encode(p).size
+        est = api.range_encode_bound_hist(p)
+        assert est >= real, (p.size, int(p[0]), est, real)
+        assert est <= api.lib().wr_range_encode_bound(p.size)
+        # tight in absolute terms: the coder's worst-case rounding loss (0.0104 bit per symbol, of which a real stream uses a
+        # twentieth) plus the flush and store-ahead slack -- 1.4 MB for a plane of 2^30 symbols, whatever its entropy
+        assert est - real <= 80 + 0.0016 * p.size, (p.size, est, real)

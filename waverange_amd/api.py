@@ -272,6 +272,18 @@ def range_encode(plane):
     return out[:n].copy()
 
 
+def range_encode_bound_hist(plane):
+    """wr_range_encode_bound_hist on the plane's own per-block histograms (counted here with numpy)."""
+    p = np.ascontiguousarray(plane, dtype=np.uint8).ravel()
+    nb = p.size // 60000 + 1
+    hist = np.zeros((nb, 256), dtype=np.uint16)
+    for b in range(nb):
+        hist[b] = np.bincount(p[b * 60000:(b + 1) * 60000], minlength=256)
+    lib().wr_range_encode_bound_hist.restype = C.c_size_t
+    lib().wr_range_encode_bound_hist.argtypes = [C.c_void_p, C.c_size_t]
+    return int(lib().wr_range_encode_bound_hist(hist.ctypes.data, p.size))
+
+
 def range_decode(stream, n):
     s = np.ascontiguousarray(stream, dtype=np.uint8).ravel()
     out = np.zeros(max(n, 1), dtype=np.uint8)

@@ -324,17 +324,47 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     wrrc::PlaneJob jobs[WR_NLAYMAX];
     wrrc::JobBatch batch;
     unsigned pool_mask = 0;  // planes the pool took
+    // Where a plane's coder writes.  The reference codes every plane into a buffer of its own and copies the streams
+    // together (wrappers.cpp:412-427); here the planes are coded at the same time, so a plane's place in data_enc is not
+    // known when its coder starts -- but an upper bound on the length of every plane before it is, from their block
+    // histograms (wrrc::encode_bound_hist: rigorous, ~0.2 % above the stream).  Plane l is coded straight into data_enc at
+    // the sum of the bounds of planes 0 .. l-1, and the gaps are closed afterwards by moving the planes down in order (a few
+    // megabytes each).  The coded bytes of a field then exist once in host memory, not twice (a 1e-7 field at 1024^3: 2 GB),
+    // and the context keeps no per-plane output buffers.  A plane whose bound does not fit under `cap` takes the old way
+    // through c->enc_buf (only then can total <= cap < sum of bounds happen).
+    std::mutex place_mu;
+    unsigned placed = 0;
+    size_t est_off[WR_NLAYMAX + 1] = {0}, est_len[WR_NLAYMAX] = {0};
+    uint8_t* plane_out[WR_NLAYMAX] = {nullptr};
+    bool direct[WR_NLAYMAX] = {false};
+    static const bool direct_ok = !(getenv("WR_ENC_DIRECT") && !atoi(getenv("WR_ENC_DIRECT")));
+    // (callable from the coder threads: the histograms of plane k and of the planes before it have been sent off)
+    auto place_plane = [&](unsigned k) -> uint8_t* {
+        std::lock_guard<std::mutex> lk(place_mu);
+        for (unsigned j = placed; j <= k; j++) {
+            if (xfer_wait(&c->x_plane[j]) != WR_OK) copy_failed[j] = 1;
+            est_len[j] = copy_failed[j] ? wrrc::encode_bound(n) : wrrc::encode_bound_hist(c->h_hist + j * hist_per_plane, n);
+            est_off[j + 1] = est_off[j] + est_len[j];
+            direct[j] = direct_ok && data_enc && est_off[j + 1] <= cap;
+            if (direct[j]) plane_out[j] = data_enc + est_off[j];
+            else plane_out[j] = ensure_enc_buf(c, (int)j, est_len[j]) == WR_OK ? c->enc_buf[j] : nullptr;
+            placed = j + 1;
+        }
+        return plane_out[k];
+    };
     auto code_group = [&](unsigned l0, unsigned l1) {
         (void)hipSetDevice(dev);
         for (unsigned l = l0; l < l1; l++)
             if (xfer_wait(&c->x_plane[l]) != WR_OK) copy_failed[l] = 1;
+        for (unsigned l = l0; l < l1; l++)
+            if (!place_plane(l)) { copy_failed[l] = 1; return; }
         sem.acquire();
         const double t = now();
         const uint8_t* syms[WR_NLAYMAX];
         uint8_t* outs[WR_NLAYMAX];
         const uint16_t* hs[WR_NLAYMAX];
         const wrrc::PlaneWindow* ios[WR_NLAYMAX];
-        for (unsigned l = l0; l < l1; l++) { syms[l - l0] = nullptr; outs[l - l0] = c->enc_buf[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; ios[l - l0] = &c->ps[l].io; }
+        for (unsigned l = l0; l < l1; l++) { syms[l - l0] = nullptr; outs[l - l0] = plane_out[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; ios[l - l0] = &c->ps[l].io; }
         wrrc::encode_planes((int)(l1 - l0), syms, n, outs, hs, lens + l0, ios);
         for (unsigned l = l0; l < l1; l++) coder_s[l] = now() - t;
         sem.release();
@@ -380,10 +410,12 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         auto submit_plane = [&](unsigned k) {
             if (handed >> k & 1) return;
             if (xfer_wait(&c->x_plane[k]) != WR_OK) { copy_failed[k] = 1; return; }
+            uint8_t* const dst = place_plane(k);
+            if (!dst || copy_failed[k]) { copy_failed[k] = 1; return; }
             handed |= 1u << k;
             wrrc::PlaneJob& j = jobs[k];
             j.kind = wrrc::PlaneJob::kEncode;
-            j.src = nullptr; j.io = &c->ps[k].io; j.dst = c->enc_buf[k]; j.n = n; j.hist = c->h_hist + k * hist_per_plane;
+            j.src = nullptr; j.io = &c->ps[k].io; j.dst = dst; j.n = n; j.hist = c->h_hist + k * hist_per_plane;
             if (wrrc::pool_submit(&j, 1, &batch)) pool_mask |= 1u << k;
             else workers.v.emplace_back(code_group, k, k + 1);  // the pool was stopped meanwhile: a thread of this call codes the plane
         };
@@ -391,7 +423,6 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             // plane l and its histograms are complete on the device: the histograms go to pinned host memory, the
             // plane's first chunk sets off into its ring, and a coder thread waits for them
             if (ready >> l & 1) return WR_OK;  // (done early, by a later plane that had to wait for device memory: before_wait)
-            if (int r = ensure_enc_buf(c, (int)l, wrrc::encode_bound(n))) return r;
             ready |= 1u << l;
             const Piece pc = {c->h_hist + l * hist_per_plane, slot->hist + l * hist_per_plane, hist_per_plane * sizeof(uint16_t)};
             if (int r = xfer_start(c, &c->x_plane[l], &pc, 1, kDown)) return r;
@@ -471,7 +502,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         if (verbose()) logs[l] = plane_log(c, (int)l, n, info, true, lens[l]);  // wrappers.cpp:401-409, 430
     }
     const double t_coded = now();
-    // concatenate the plane streams (wrappers.cpp:412-427); gigabytes at 1024^3, so one copier per plane
+    // concatenate the plane streams (wrappers.cpp:412-427)
     size_t total = 0, offs[WR_NLAYMAX] = {0};
     for (unsigned l = 0; l < info->nlay; l++) {
         offs[l] = total;
@@ -479,18 +510,19 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         info->len_enc_vec[l] = lens[l];
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
     }
+    for (unsigned l = 0; l < info->nlay; l++)  // (cannot happen: the bound is rigorous; if it did, a neighbour's bytes are gone)
+        if (lens[l] > est_len[l]) return fail(WR_ERR_OVERFLOW, "internal: plane " + std::to_string(l) + " outgrew the bound computed from its histograms");
     if (total > cap) return fail(WR_ERR_OVERFLOW, "Error: encoded array is too large. Use larger SAFETY_BUFFER_FACTOR");
-    try {
-        Workers copiers;
-        for (unsigned l = 1; l < info->nlay; l++)
-            copiers.v.emplace_back([&, l]() { memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]); });
-        if (info->nlay) memcpy(data_enc, c->enc_buf[0], lens[0]);
-    } catch (const std::exception&) {  // no thread to be had: copy here
-        for (unsigned l = 0; l < info->nlay; l++) memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]);
-    }
-    // The per-plane coder output has been copied out: hand its pages back (only coded bytes were ever touched, but a
-    // noise plane's gigabyte would otherwise stay resident in every context that once coded one)
+    // close the gaps: plane l moves down by what the planes before it stayed below their bounds.  In plane order, one after
+    // the other: plane l's new place may still hold the end of plane l-1's old one.
     for (unsigned l = 0; l < info->nlay; l++) {
+        if (!direct[l]) memcpy(data_enc + offs[l], c->enc_buf[l], lens[l]);
+        else if (est_off[l] != offs[l]) memmove(data_enc + offs[l], data_enc + est_off[l], lens[l]);
+    }
+    // (a plane that went through c->enc_buf: hand its pages back, a noise plane's gigabyte would otherwise stay resident in
+    // every context that once coded one)
+    for (unsigned l = 0; l < info->nlay; l++) {
+        if (direct[l]) continue;
         const uintptr_t a = ((uintptr_t)c->enc_buf[l] + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)c->enc_buf[l] + lens[l]) & ~(uintptr_t)4095;
         if (e > a && e - a >= ((size_t)64 << 20)) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_DONTNEED);
     }

@@ -8,6 +8,7 @@ using namespace wri;
 extern "C" {
 
 size_t wr_range_encode_bound(size_t n) { return wrrc::encode_bound(n); }
+size_t wr_range_encode_bound_hist(const unsigned short* hists, size_t n) { return wrrc::encode_bound_hist(hists, n); }
 size_t wr_range_encode(const unsigned char* sym, size_t n, unsigned char* out) { return wrrc::encode_plane(sym, n, out, nullptr); }
 size_t wr_range_decode(const unsigned char* in, size_t len, unsigned char* sym, size_t n) { return wrrc::decode_plane(in, len, sym, n); }
 void wr_range_encode_multi(int count, const unsigned char* const* sym, size_t n, unsigned char* const* out, size_t* lens)

@@ -20,6 +20,9 @@ constexpr int kMaxDecStreams = 4;   // ... by a pool worker's decoder loop (5 an
 
 // upper bound on the stream length for n symbols
 size_t encode_bound(size_t n);
+// the same for a plane whose per-block byte histograms are known (uint16[256] per block, n/60000+1 blocks, as encode_plane
+// takes them): the blocks' entropy plus headers plus the coder's worst-case rounding loss -- within ~0.2 % of the stream
+size_t encode_bound_hist(const uint16_t* hists, size_t n);
 
 // Windowed access to the symbol side of a plane that is not in host memory as a whole (it lives in device memory and
 // passes through a small pinned ring, wr_pipeline.cpp).  `count` comes in as what is left of the plane from `first` on and
