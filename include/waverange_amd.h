@@ -225,6 +225,9 @@ int wr_dev_copy(wr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes); 
 /* measurement hook: copies through the compute units with `workgroups` workgroups on the context's stream, without
  * waiting (either side may be pinned host memory; 16-byte granularity) */
 int wr_dev_copy_kernel(wr_ctx *ctx, void *dst, const void *src, size_t bytes, int workgroups);
+/* measurement hook: `workgroups` workgroups stay on the device for `ms` milliseconds on the context's stream, without waiting
+ * (mode 0: a chain of fp64 arithmetic, 1: asleep) -- what it takes to bring the shader clock up before a kernel stage */
+int wr_dev_burn(wr_ctx *ctx, double ms, int mode, int workgroups);
 /* max|a-b| and max|a| over n doubles (accuracy check of a reconstruction, "L-inf vs tol") */
 int wr_dev_linf(wr_ctx *ctx, const double *d_a, const double *d_b, size_t n, double *max_abs_diff,
                 double *max_abs_a);

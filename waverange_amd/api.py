@@ -608,6 +608,10 @@ class Context:
         _check(lib().wr_decode_finish_device(self.h, buf.ptr, C.byref(tm)))
         return tm.as_dict()
 
+    def burn(self, ms, mode=0, workgroups=1024):
+        lib().wr_dev_burn.argtypes = [_vp, C.c_double, C.c_int, C.c_int]
+        _check(lib().wr_dev_burn(self.h, ms, mode, workgroups))
+
     def test_stale_window(self, n):
         """Test hook: the window handle of a finished call against the plane of the next one (must be refused)."""
         _check(lib().wr_test_stale_window(self.h, n))

@@ -49,12 +49,22 @@ constexpr int TXP = 64;             // x-pairs per tile
 #endif
 constexpr int TYP = WR_FTYP;        // y-pairs per tile
 constexpr int RX = TXP + 4;         // raw pairs per staged row: 2 + 64 + 2
+// Pitches of the two LDS arrays of the forward kernel.  In the x lifting the eight lanes that a ds_read_b128 / ds_write_b128
+// serves together hold the same columns of eight consecutive ROWS (below), so a row pitch of 8 x 128 + 80 bytes (raw: 69
+// chunks, the 69th a dummy) resp. 8 x 128 + 16 bytes (xl: 130 doubles) puts their 16-byte pieces into eight different
+// quarters of the 32 banks: no conflicts (the r02 layout, two adjacent pairs per lane at a 32-byte lane stride, had two-way
+// conflicts by construction: 26 % of its LDS cycles).
+constexpr int RXP = RX + 1;         // staged row pitch in 16-byte chunks (69)
+constexpr int XLP = 2 * TXP + 2;    // xl row pitch in doubles (130)
 constexpr int RROWS = 2 * TYP + 7;  // staged rows: 4 + 32 + 3
-constexpr int NCHUNK = RROWS * RX;  // 16-byte chunks per plane (2652)
+constexpr int NCHUNK = RROWS * RXP; // 16-byte chunks per plane (2691)
 constexpr int NTHR = 32 * TYP;      // one thread = one x-pair x two y-pairs
 constexpr int NWAVE = NTHR / 64;
-constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (3)
-constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * 2 * TXP * 8;
+constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (6)
+constexpr int XBLOCKS = 2 * ((RROWS + 7) / 8);   // 8-row x 32-pair blocks of the x lifting (10)
+constexpr int XB2 = XBLOCKS - NWAVE;             // blocks left for a second round (2)
+static_assert(XB2 >= 0 && XB2 <= NWAVE, "x-lifting blocks: at most two rounds");
+constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * XLP * 8;
 
 // blockIdx.x -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (b % 8 says which
 // share an L2), and the j-th workgroups of all XCDs run at the same time.  Tiles next to each other read the same
@@ -114,6 +124,25 @@ __device__ inline void lift_fwd_two(const double s[6], const double d[5], double
     lo1 = s2d * WR_ZETA; hi1 = d2d * WR_IZETA;
 }
 
+// forward lifting of four adjacent pairs from s[-2..5], d[-2..4]: 22 lifting steps, 5.5 per pair (the same expression tree
+// per output as lift_fwd_two and as the reference's line loop: the outputs are bit-identical)
+__device__ inline void lift_fwd_four(const double s[8], const double d[7], double lo[4], double hi[4])
+{
+    double d1[7], s1[7], d2[6];
+#pragma unroll
+    for (int k = 0; k < 7; k++) d1[k] = d[k] + WR_ALPHA * (s[k + 1] + s[k]);
+#pragma unroll
+    for (int k = 1; k < 7; k++) s1[k] = s[k] + WR_BETA * (d1[k] + d1[k - 1]);
+#pragma unroll
+    for (int k = 1; k < 6; k++) d2[k] = d1[k] + WR_GAMMA * (s1[k + 1] + s1[k]);
+#pragma unroll
+    for (int k = 2; k < 6; k++) {
+        const double s2 = s1[k] + WR_DELTA * (d2[k] + d2[k - 1]);
+        lo[k - 2] = s2 * WR_ZETA;
+        hi[k - 2] = d2[k] * WR_IZETA;
+    }
+}
+
 }  // namespace
 
 // MM_IN / MM_OUT: also reduce min/max of the samples read (the whole level input: level 0 = the field) / of the
@@ -140,7 +169,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
 #endif
     extern __shared__ double2 lds2[];
     double2* raw = lds2;                                          // [2][RROWS][RX]
-    double* xl = reinterpret_cast<double*>(lds2 + 2 * NCHUNK);   // [RROWS][2*TXP]
+    double* xl = reinterpret_cast<double*>(lds2 + 2 * NCHUNK);   // [RROWS][XLP]: [low 64 | high 64 | 2 unused]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + TXP - 1) / TXP;
@@ -161,8 +190,8 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
 #pragma unroll
     for (int k = 0; k < KCH; k++) {
         const int c = tid + NTHR * k;
-        const int row = c / RX, pr = c - row * RX;
-        const int gy = mirror(2 * py0 - 4 + row, n2);
+        const int row = c / RXP, pr = c - row * RXP;  // (pr == RX: the dummy chunk of the row pitch, any valid address)
+        const int gy = mirror(2 * py0 - 4 + (row < RROWS ? row : 0), n2);
         int gx = 2 * (px0 - 2 + pr);
         gx = gx < 0 ? 0 : (gx > n1 - 2 ? n1 - 2 : gx);
         offa[k] = (int)(gy * s_sy) + gx;
@@ -191,11 +220,13 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
         double2* rp = raw + p * NCHUNK;
         if (left_edge | right_edge) {
             // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
-            // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3])
-            if (lane < 4 * ((RROWS + 2 * NWAVE - 1) / (2 * NWAVE))) {
-                const int row = 2 * (w + NWAVE * (lane >> 2)) + ((lane >> 1) & 1);
-                if (row < RROWS) {
-                    double2* e = rp + row * RX;
+            // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3]).
+            // Wave w patches the rows it reads below: the row blocks w and (w < XB2 ? NWAVE + w : none).
+            if (lane < 32) {
+                const int blk = (lane < 16) ? w : (w < XB2 ? NWAVE + w : -1);
+                const int row = (blk >> 1) * 8 + ((lane >> 1) & 7);
+                if (blk >= 0 && row < RROWS) {
+                    double2* e = rp + row * RXP;
                     if (left_edge) e[lane & 1] = (lane & 1) ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
                     if (right_edge) {
                         double2* f = e + iL + 3 + (lane & 1);
@@ -204,35 +235,39 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                 }
             }
         }
-        // two adjacent x-pairs per lane (14 lifting steps instead of 20): a wave covers two rows
-        // per round, lanes 0-31 the first, lanes 32-63 the second
-        const int half = lane >> 5, jp = (lane & 31) * 2;  // first of this lane's two x-pairs
-        auto two_rows = [&](int row) {
-            const double2* r = rp + row * RX + jp;
-            const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5];
-            if (MM_IN) {  // v2, v3 are this lane's own two pairs: all lanes and rows together cover every sample read
-                in_lo = fmin(fmin(in_lo, v2.x), fmin(v2.y, fmin(v3.x, v3.y)));
-                in_hi = fmax(fmax(in_hi, v2.x), fmax(v2.y, fmax(v3.x, v3.y)));
+        // Four adjacent x-pairs per lane: 22 lifting steps where two lanes with two pairs each need 28, and 8 chunk reads
+        // where they need 12.  A wave takes a block of 8 rows x 8 lane columns (32 x-pairs = half the tile's width): lane =
+        // 8 * column + row, so that the 8 lanes an LDS instruction serves together differ in the ROW (see RXP / XLP).
+        // 39 rows x 2 halves = 10 blocks: block w for every wave, blocks 8 and 9 for waves 0 and 1.
+        const int lrow = lane & 7, lcol = lane >> 3;
+        auto block = [&](int blk) {
+            const int row = (blk >> 1) * 8 + lrow;
+            if (row >= RROWS) return;
+            const int jq = ((blk & 1) * 8 + lcol) * 4;  // first of this lane's four x-pairs
+            const double2* r = rp + row * RXP + jq;
+            const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5], v6 = r[6], v7 = r[7];
+            if (MM_IN) {  // v2 .. v5 are this lane's own pairs: all lanes and rows together cover every sample read
+                in_lo = fmin(fmin(fmin(in_lo, v2.x), fmin(v2.y, fmin(v3.x, v3.y))), fmin(fmin(v4.x, v4.y), fmin(v5.x, v5.y)));
+                in_hi = fmax(fmax(fmax(in_hi, v2.x), fmax(v2.y, fmax(v3.x, v3.y))), fmax(fmax(v4.x, v4.y), fmax(v5.x, v5.y)));
             }
-            const double s[6] = {v0.x, v1.x, v2.x, v3.x, v4.x, v5.x};
-            const double d[5] = {v0.y, v1.y, v2.y, v3.y, v4.y};
-            double lo0, hi0, lo1, hi1;
-            lift_fwd_two(s, d, lo0, hi0, lo1, hi1);
-            *reinterpret_cast<double2*>(xl + row * (2 * TXP) + jp) = make_double2(lo0, lo1);
-            *reinterpret_cast<double2*>(xl + row * (2 * TXP) + TXP + jp) = make_double2(hi0, hi1);
+            const double sv[8] = {v0.x, v1.x, v2.x, v3.x, v4.x, v5.x, v6.x, v7.x};
+            const double dv[7] = {v0.y, v1.y, v2.y, v3.y, v4.y, v5.y, v6.y};
+            double lo[4], hi[4];
+            lift_fwd_four(sv, dv, lo, hi);
+            double* o = xl + row * XLP + jq;
+            *reinterpret_cast<double2*>(o) = make_double2(lo[0], lo[1]);
+            *reinterpret_cast<double2*>(o + 2) = make_double2(lo[2], lo[3]);
+            *reinterpret_cast<double2*>(o + TXP) = make_double2(hi[0], hi[1]);
+            *reinterpret_cast<double2*>(o + TXP + 2) = make_double2(hi[2], hi[3]);
         };
-        constexpr int XR2 = (RROWS + 2 * NWAVE - 1) / (2 * NWAVE);  // rounds of 2*NWAVE rows (3)
-#pragma unroll
-        for (int k = 0; k < XR2; k++) {
-            const int row = 2 * (w + NWAVE * k) + half;
-            if (row < RROWS) two_rows(row);
-        }
+        block(w);
+        if (w < XB2) block(NWAVE + w);
     };
     // y lifting of this thread's two y-pairs (2w, 2w+1) for its two x columns:
     // out[4*yp + {0,1,2,3}] = {LL, HL, LH, HH} of y-pair yp
     auto ylift = [&](double out[8]) {
-        const double* c0 = xl + (4 * w) * (2 * TXP) + lane;
-        constexpr int P = 2 * TXP;
+        const double* c0 = xl + (4 * w) * XLP + lane;
+        constexpr int P = XLP;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const double* c = c0 + h * TXP;

@@ -92,6 +92,8 @@ void synth_field(double* out, int nx, int ny, int nz, unsigned long long seed, i
 // per-60000-symbol-block byte histograms of a plane (feeds the host range coder's model):
 // hist[b*256 + v] = count of value v in block b (uint16, block size < 65536)
 void block_histograms(const PlaneRef& q, size_t n, uint16_t* hist, hipStream_t st);
+// keeps `workgroups` workgroups of 256 lanes on the device for `ms` milliseconds (mode 0: fp64 arithmetic, 1: asleep)
+void burn(double ms, int mode, int workgroups, double* sink, hipStream_t st);
 // bytes (a multiple of 16, 16-byte aligned pointers) copied by `workgroups` workgroups; src / dst may be pinned host memory
 void copy_kernel(void* dst, const void* src, size_t bytes, int workgroups, hipStream_t st);
 

@@ -762,6 +762,27 @@ void copy_kernel(void* dst, const void* src, size_t bytes, int workgroups, hipSt
     hipLaunchKernelGGL(k_copy16, dim3(workgroups), dim3(256), 0, st, static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16);
 }
 
+// Clock keeper: occupies every CU for `ticks` of the 100 MHz wall clock and leaves -- mode 0 with a chain of fp64 multiply-adds
+// (real load), mode 1 asleep (s_sleep between looks at the clock).  Every wave leaves by the clock, whatever it computed.
+__global__ __launch_bounds__(256) void k_burn(long long ticks, int mode, double* sink)
+{
+    const long long t0 = wall_clock64();
+    double a = 1.0 + threadIdx.x * 1e-9, b = 0.999999;
+    while (wall_clock64() - t0 < ticks) {
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) a = a * b + 1e-9;
+        } else
+            __builtin_amdgcn_s_sleep(64);
+    }
+    if (a == 123.456) sink[0] = a;  // (never: keeps the chain alive)
+}
+
+void burn(double ms, int mode, int workgroups, double* sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_burn, dim3(workgroups), dim3(256), 0, st, (long long)(ms * 1e5), mode, sink);
+}
+
 void block_histograms(const PlaneRef& q, size_t n, uint16_t* hist, hipStream_t st)
 {
     const int nb = (int)(n / 60000 + 1);  // includes the (possibly empty) final block

@@ -944,6 +944,15 @@ int wr_dev_copy_kernel(wr_ctx* c, void* dst, const void* src, size_t bytes, int 
     return WR_OK;
 }
 
+int wr_dev_burn(wr_ctx* c, double ms, int mode, int workgroups)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    if (ms < 0 || ms > 1000 || workgroups < 1) return fail(WR_ERR_ARG, "burn: 0..1000 ms, at least one workgroup");
+    wrk::burn(ms, mode, workgroups, c->d_partial, c->stream);
+    HIPCHK(hipGetLastError());
+    return WR_OK;
+}
+
 int wr_dev_copy(wr_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (int rc = ctx_bind(c)) return rc;
