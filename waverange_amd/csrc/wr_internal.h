@@ -145,6 +145,7 @@ struct DevPool {
     std::mutex gate_mu; std::condition_variable gate_cv;
     int gate_waiting = 0;
     double gate_last_end = 0;
+    std::atomic<double> last_stage_end{0};  // when the last kernel stage of a host call gave up cu_mu (clock_warmup)
     std::atomic<int> active_calls{0};  // wr_encode_* / wr_decode_* calls inside the library on this device
     DevPlanes planes;
 };
@@ -380,6 +381,7 @@ struct StageGate {  // RAII pair of the two: an exception between them must not 
     StageGate(const StageGate&) = delete;
     StageGate& operator=(const StageGate&) = delete;
 };
+void clock_warmup(wr_ctx* c);       // first thing in a host call's kernel stage (cu_mu held)
 int check_dims(int nx, int ny, int nz, const void* dev_ptr);
 
 struct Sem {  // tiny counting semaphore limiting concurrent range-coder threads

@@ -699,6 +699,23 @@ void stage_done(DevPool* p)
     p->gate_last_end = now();
 }
 
+// The shader clock of an idle GPU is down, and it takes ~30 ms of load to come all the way up -- longer than a whole
+// kernel stage; the transforms (half VALU issue) run 20-30 % slower at the start of a stage than back to back
+// (tools/clock_burn.py, profiles/r04/c_clock_burner_before_the_transform.txt: forward 4.91 ms cold, 3.77 after 10 ms of fp64
+// arithmetic on every CU, 3.68 after 20 ms, 3.64 warm; waves that merely occupy the CUs asleep do nothing for the clock).
+// The host coder is the long pole of the pipeline and the GPU idles 95 % of the time, so a stage that finds it idle spends
+// WR_CLOCK_WARMUP_MS (default 15, 0: off) of that idle time on a burner kernel in front of its first kernel.  Called with
+// DevPool::cu_mu held: nothing else computes on the device meanwhile.
+void clock_warmup(wr_ctx* c)
+{
+    static const double ms = []() { const char* e = getenv("WR_CLOCK_WARMUP_MS"); const double v = e ? atof(e) : 15.0; return v < 0 ? 0.0 : (v > 200 ? 200.0 : v); }();
+    if (ms <= 0) return;
+    DevPool* p = c->pool;
+    if (now() - p->last_stage_end.load() < 0.004) return;  // a stage has just ended: the clock is up
+    wrk::burn(ms, 0, 1024, c->d_partial, c->stream);
+    (void)hipGetLastError();
+}
+
 int check_dims(int nx, int ny, int nz, const void* dev_ptr)
 {
     if (nx < 1 || ny < 1 || nz < 1) return fail(WR_ERR_ARG, "non-positive dimension");
