@@ -897,6 +897,70 @@ void decode_symbols_multi(Dec* const* ds, uint8_t* const* dst, const BlockModel*
     for (int k = 0; k < NS; k++) { ds[k]->low = low[k]; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
 }
 
+// The same loop for blocks without dominant symbols and without a usable bucket table -- noise planes, a third of the
+// pool's worker-seconds -- on a different representation of the decoder's state.  rangecod.c feeds `low` from a bit string
+// that starts 7 bits into a byte (rangecod.c:297-299: low = low << 8 | (buffer << 7 & 0xff); buffer = next byte; low |=
+// buffer >> 1), so every renormalisation step looks at two stream bytes and shifts.  Carry the one bit of `buffer` that
+// `low` has not taken yet along with it: L2 = low << 1 | (buffer & 1).  Then the step is byte-aligned,
+//     L2' = (low' << 1) | (next & 1) = (low << 9) | ((buffer & 1) << 8) | next = (L2 << 8) | next
+// -- one byte load, one shift, one or; low = L2 >> 1 where the arithmetic wants it, and low -= t becomes L2 -= 2 t.
+// (L2 < 2 * range <= 2^32, and < 2^25 whenever a step shifts it.)  15 instructions less per symbol than the loop above.
+template <int NS>
+void decode_symbols_noise(Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
+{
+    uint32_t low2[NS], range[NS];
+    const uint8_t* p[NS];
+    const BlockModel* mod[NS];
+    uint8_t* sym[NS];
+    for (int k = 0; k < NS; k++) {
+        low2[k] = (ds[k]->low << 1) | (ds[k]->held & 1u); range[k] = ds[k]->range; p[k] = ds[k]->in + ds[k]->pos;
+        mod[k] = ms[k]; sym[k] = dst[k];
+    }
+    for (uint32_t i = 0; i < kBlock; i++) {
+#pragma GCC unroll 8
+        for (int k = 0; k < NS; k++) {
+            const BlockModel* const m = mod[k];
+            uint32_t l2 = low2[k], rg = range[k];
+            const uint8_t* q = p[k];
+            // range / 60000 of either outcome beside the compare (see above)
+            uint32_t help = rg / kBlock;
+            const uint32_t h_shifted = (rg << 8) / kBlock, rg_shifted = rg << 8;
+            const uint32_t fed = (l2 << 8) | q[0];
+#if defined(__x86_64__)
+            // one compare decides all four: the state, the range, its quotient and whether the stream pointer moves on
+            __asm__("cmpl $0x800001, %[rg]\n\t"
+                    "cmovbl %[fed], %[l2]\n\t"
+                    "cmovbl %[hs], %[help]\n\t"
+                    "cmovbl %[rgs], %[rg]\n\t"
+                    "adcq $0, %[q]"
+                    : [l2] "+r"(l2), [help] "+r"(help), [rg] "+r"(rg), [q] "+r"(q)
+                    : [fed] "r"(fed), [hs] "r"(h_shifted), [rgs] "r"(rg_shifted)
+                    : "cc");
+#else
+            const uint32_t sh = rg <= kBottom;
+            l2 = sh ? fed : l2; help = sh ? h_shifted : help; rg = sh ? rg_shifted : rg; q += sh;
+#endif
+            if (__builtin_expect(rg <= kBottom, 0)) {
+                do {
+                    l2 = (l2 << 8) | q[0];
+                    rg <<= 8;
+                    q++;
+                } while (rg <= kBottom);
+                help = rg / kBlock;
+            }
+            const uint32_t cf = (l2 >> 1) / help;
+            const uint32_t c = m->lookup[cf];
+            const uint32_t t = help * m->tab[c].lt;
+            l2 -= t + t;
+            rg = (c != m->top) ? help * m->tab[c].sy : rg - t;
+            sym[k][i] = (uint8_t)c;
+            low2[k] = l2; range[k] = rg; p[k] = q;
+        }
+    }
+    for (int k = 0; k < NS; k++) { ds[k]->low = low2[k] >> 1; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
+}
+const bool kNoiseLoop = !(getenv("WR_RC_NOISE_LOOP") && !atoi(getenv("WR_RC_NOISE_LOOP")));
+
 using MultiFn = void (*)(Dec* const*, uint8_t* const*, const BlockModel* const*);
 template <int NS, unsigned... M>
 constexpr MultiFn multi_entry(unsigned mask, std::integer_sequence<unsigned, M...>)
@@ -906,8 +970,17 @@ constexpr MultiFn multi_entry(unsigned mask, std::integer_sequence<unsigned, M..
 }
 inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
 {
-    unsigned mask = 0;
-    for (int k = 0; k < count; k++) mask |= (ms[k]->mps_on ? 1u : 0u) << k;
+    unsigned mask = 0, buckets = 0;
+    for (int k = 0; k < count; k++) { mask |= (ms[k]->mps_on ? 1u : 0u) << k; buckets |= ms[k]->use_buckets ? 1u : 0u; }
+    if (!mask && !buckets && kNoiseLoop) {
+        switch (count) {
+        case 1: decode_symbols_noise<1>(ds, dst, ms); break;
+        case 2: decode_symbols_noise<2>(ds, dst, ms); break;
+        case 3: decode_symbols_noise<3>(ds, dst, ms); break;
+        default: decode_symbols_noise<4>(ds, dst, ms); break;
+        }
+        return;
+    }
     switch (count) {
     case 1: multi_entry<1>(mask, std::make_integer_sequence<unsigned, 2>())(ds, dst, ms); break;
     case 2: multi_entry<2>(mask, std::make_integer_sequence<unsigned, 4>())(ds, dst, ms); break;
