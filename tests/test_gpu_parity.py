@@ -525,3 +525,50 @@ def test_fortran_example_field(ctx, golden):
     buf.free()
     assert sha(dec) == rec["decoded_sha256"]
     assert np.abs(dec - f).max() / np.abs(f).max() == rec["linf_rel"] < rec["tolrel"]
+
+
+QUANT_PATH_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from util import bits_equal
+from waverange_amd import api, synth
+from oracle.loader import Oracle
+api.set_verbosity(0)
+o = Oracle()
+with api.Context(0) as c:
+    for shape, tol in (((130, 70, 34), 1e-10), ((128, 64, 80), 1e-16), ((200, 120, 72), 1e-6), ((37, 21, 13), 1e-9), ((61, 1, 1), 1e-7)):
+        f = synth.field(*shape, seed=99)
+        want = o.encode(f, tol)
+        for keep in (True, False):
+            buf = c.to_device(f)
+            c.set_keep_residual(keep)
+            enc, _ = c.encode(buf, f.shape, tol)
+            assert enc["nlay"] == want["nlay"] and list(enc["len_enc_vec"]) == list(want["len_enc_vec"]), (shape, tol)
+            assert bits_equal(enc["deps_vec"], want["deps_vec"]) and bits_equal(enc["minval_vec"], want["minval_vec"]), (shape, tol)
+            assert np.array_equal(enc["data"], want["data"]), (shape, tol, "coded bytes")
+            if keep:
+                assert bits_equal(buf.download(np.float64, f.size), want["residual"]), (shape, tol, "residual")
+            buf.free()
+        # host entry point (block histograms from the quantizer, planes through the windows)
+        enc, _ = c.encode_host(f, tol)
+        assert np.array_equal(enc["data"], want["data"]), (shape, tol, "host entry point")
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{}, {"WR_TEST_ZERO_MIN_PATH": "1"}, {"WR_QUANT_INPLACE": "1"}, {"WR_PLANE_CHUNK_MB": "1"}],
+                         ids=["recompute", "rare_path_after_every_plane", "in_place", "chunked_planes"])
+def test_quantizer_without_a_residual_array(env, tmp_path):
+    """The quantizer planes are cut from residuals that are recomputed from the coefficient array (k_quant_blk: 9 instead of
+    17 bytes per element and plane), with the block histograms written on the way; the reference updates the array in place
+    after every plane (wrappers.cpp:397-398).  Same header scalars, coded bytes and final residual as the oracle -- for up to
+    eight planes, odd sizes (tails of coding blocks and of 16-byte pieces), planes in 1 MiB chunks (blocks that straddle
+    two), with the residual wanted and not; when the rare path that needs the residual in memory between two planes is taken
+    after EVERY plane (sign of a zero minimum: residual_apply, then in place); and with the in-place kernels alone."""
+    import os, subprocess, sys
+    from util import ROOT
+    script = tmp_path / "quant_paths.py"
+    script.write_text(QUANT_PATH_WORKER % dict(root=ROOT))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

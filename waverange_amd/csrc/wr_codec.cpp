@@ -67,14 +67,16 @@ struct Cutoff {
     int count() const { return mx * my * mz; }
 };
 
-// Kernel stage of the encoder (call with the slot leased and DevPool::cu_mu held).  Two hooks for the full
-// pipeline: after_quant(l) is called right after plane l's quantizer kernel and the read-back of the next
-// plane's min/max have been enqueued (the block histograms are enqueued there, behind the read-back);
+// Kernel stage of the encoder (call with the slot leased and DevPool::cu_mu held).  Hooks for the full
+// pipeline: hist_buf(l) says where plane l's block histograms go on the device (nullptr: nobody wants them);
+// after_quant(l, hist_done) is called right after plane l's quantizer kernel and the read-back of the next
+// plane's min/max have been enqueued (hist_done: the quantizer has written the histograms on its way; otherwise they
+// are enqueued there, behind the read-back);
 // plane_ready(l, last) is called from the host once everything enqueued for plane l has completed on the
 // device (the download starts there).  *resid = where the coefficient array / residual lives afterwards.
-template <class PlaneBuf, class AfterQuant, class PlaneReady>
+template <class PlaneBuf, class HistBuf, class AfterQuant, class PlaneReady>
 int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int nz, int wtflag, const Cutoff& cut,
-                       PlaneBuf plane_buf, wr_enc_info* info, wr_timings* tm, AfterQuant after_quant, PlaneReady plane_ready,
+                       PlaneBuf plane_buf, HistBuf hist_buf, wr_enc_info* info, wr_timings* tm, AfterQuant after_quant, PlaneReady plane_ready,
                        double** resid)
 {
     // minimum cutoff = the global relative tolerance (wrappers.cpp:288-290)
@@ -162,18 +164,25 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
     }
     unsigned ilay = 0;
     float quant_ms = 0;
+    // The residual is not kept in memory between planes (wr_kernels.hip: k_quant_blk): d_fld stays the coefficient array, every
+    // plane's kernel redoes the subtractions of the planes in `prev`.  The local-cutoff quantizer and unaligned caller
+    // pointers keep the reference's form (the array is updated in place after every plane).
+    wrk::QuantPrev prev;
     for (;;) {
         PlaneStep s = plane_step(lo, hi, info->tolabs, ilay);
         info->minval_vec[ilay] = s.minval;
         info->deps_vec[ilay] = s.deps;
         if (verbose()) { printf("min=%g max=%g\n", lo, hi); printf("ilay=%u deps=%g\n", ilay, s.deps); }
-        const bool resid_upd = !s.last || c->keep_residual;
         const wrk::PlaneRef* const d_plane = plane_buf(ilay);  // device memory of this plane (the error is set if there is none)
         if (!d_plane) return WR_ERR_HIP;
         if (!wrk::plane_ref_covers(*d_plane, n)) return fail(WR_ERR_HIP, "internal: the device buffer of plane " + std::to_string(ilay) + " has a hole");
         // (a chunked plane is only ever indexed through its table: the direct-form kernels for unaligned pointers take one array)
         if (d_plane->shift < 63 && (((uintptr_t)d_fld | (uintptr_t)d_plane->chunk[0]) & 15)) return fail(WR_ERR_ARG, "internal: chunked plane with an unaligned pointer");
-        launch_note(c, local ? "quant_local" : resid_upd ? "quant<1>" : "quant<0>", (int)ilay, d_fld, n, c->d_partial, *d_plane);
+        const bool blk = !local && (prev.n > 0 || ilay == 0) && wrk::quantize_plane_blk_ok(d_fld, *d_plane);
+        const bool resid_upd = blk ? (s.last && c->keep_residual) : (!s.last || c->keep_residual);
+        uint16_t* const d_hist = blk ? hist_buf(ilay) : nullptr;
+        launch_note(c, local ? "quant_local" : blk ? (resid_upd ? "quant_blk<1>" : "quant_blk<0>") : resid_upd ? "quant<1>" : "quant<0>", (int)ilay, d_fld, n,
+                    c->d_partial, *d_plane);
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
         if (local) {
             wrk::LocalCutoff lc;
@@ -185,15 +194,17 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
             lc.span = hi - lo;
             wrk::quantize_plane_local(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, d_plane->chunk[0], lc,  // (one array: plane_prepare(contiguous))
                                       c->d_partial, c->h_result_dev, c->stream);
-        } else
-        wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, *d_plane, resid_upd,
-                            c->d_partial, c->h_result_dev, c->stream);
+        } else if (blk)
+            wrk::quantize_plane_blk(d_fld, n, prev, s.aopt, s.bopt, s.deps, s.minval, *d_plane, resid_upd, !s.last, d_hist, c->d_partial,
+                                    c->h_result_dev, c->stream);
+        else
+            wrk::quantize_plane(d_fld, n, s.aopt, s.bopt, s.deps, s.minval, *d_plane, resid_upd, c->d_partial, c->h_result_dev, c->stream);
         HIPCHK(hipEventRecord(c->ev_b, c->stream));
         if (hipGetLastError() != hipSuccess) return fail(WR_ERR_HIP, "quantizer launch failed" + launch_describe(c));
         // the next plane's min/max is in host memory when this event fires (the reduction stores it there); what
         // after_quant enqueues runs behind it
         HIPCHK(hipEventRecord(c->ev_mm, c->stream));
-        if (int rc = after_quant(ilay)) return rc;
+        if (int rc = after_quant(ilay, d_hist != nullptr)) return rc;
         HIPCHK(hipEventRecord(c->ev_plane[ilay], c->stream));
         HIPCHK(hipEventSynchronize(c->ev_mm));
         HIPCHK(hipEventElapsedTime(&ms, c->ev_a, c->ev_b)); quant_ms += ms;
@@ -205,10 +216,15 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
             ilay++;
             break;
         }
+        if (blk) prev.push(s.aopt, s.bopt, s.deps, s.minval);
         ilay++;
         lo = c->h_result[0]; hi = c->h_result[1];
-        if (lo == 0.0)  // sign of a zero minimum: rare path, goes through the full read-back
+        // (WR_TEST_ZERO_MIN_PATH=1: tests take the rare path below after every plane)
+        static const bool force_rare = getenv("WR_TEST_ZERO_MIN_PATH") && atoi(getenv("WR_TEST_ZERO_MIN_PATH"));
+        if (lo == 0.0 || force_rare) {  // sign of a zero minimum: rare path, goes through the full read-back -- of the residual, in memory
+            if (prev.n) { wrk::residual_apply(d_fld, n, prev, c->stream); prev.n = 0; }  // (the planes from here on update it in place)
             if (int rc = read_minmax(c, d_fld, n, true, &lo, &hi)) return rc;
+        }
     }
     info->nlay = (unsigned char)ilay;
     if (tm) tm->quant_ms = quant_ms;
@@ -236,8 +252,9 @@ int wr_dev_encode_planes(wr_ctx* c, double* d_fld, int nx, int ny, int nz, int w
     const size_t pitch = wr_plane_pitch((size_t)nx * ny * nz);
     wrk::PlaneRef refs[WR_NLAYMAX];
     for (int l = 0; l < WR_NLAYMAX; l++) refs[l] = wrk::plane_ref(d_planes + l * pitch);
-    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, [&](unsigned l) { return &refs[l]; }, info, nullptr,
-                                [](unsigned) { return WR_OK; }, [](unsigned, bool) { return WR_OK; }, &resid);
+    int rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, [&](unsigned l) { return &refs[l]; },
+                                [](unsigned) { return (uint16_t*)nullptr; }, info, nullptr, [](unsigned, bool) { return WR_OK; },
+                                [](unsigned, bool) { return WR_OK; }, &resid);
     if (rc == WR_OK && resid != d_fld && info->nlay)  // d_fld holds the residual afterwards (header contract)
         if (hipMemcpyAsync(d_fld, resid, (size_t)nx * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             rc = fail(WR_ERR_HIP, "residual copy failed");
@@ -394,7 +411,9 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             local.h2d_ms = (float)c->x_field.ms;
         }
         double* resid = d_fld;
-        auto after_quant = [&](unsigned l) -> int {
+        auto hist_buf = [&](unsigned l) { return slot->hist + l * hist_per_plane; };
+        auto after_quant = [&](unsigned l, bool hist_done) -> int {
+            if (hist_done) return WR_OK;  // the quantizer wrote them on its way (k_quant_blk)
             // block histograms of plane l on the kernel stream, behind the read-back of the next plane's min/max
             launch_note(c, "hist", (int)l, slot->hist + l * hist_per_plane, n, nullptr, c->ps[l].ref);
             wrk::block_histograms(c->ps[l].ref, n, slot->hist + l * hist_per_plane, c->stream);
@@ -454,7 +473,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             StageGate gate(pool);
             cu.lock();
             clock_warmup(c);
-            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, info, &local, after_quant, plane_ready, &resid);
+            rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, hist_buf, info, &local, after_quant, plane_ready, &resid);
             if (hipStreamSynchronize(c->stream) != hipSuccess && rc == WR_OK) rc = fail(WR_ERR_HIP, "the encoder's kernel stage failed on the device" + launch_describe(c));
             if (rc == WR_OK && c->keep_residual && info->nlay && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
                 if (hipMemcpyAsync(fld.dev, resid, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||

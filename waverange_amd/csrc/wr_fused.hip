@@ -61,9 +61,13 @@ constexpr int NCHUNK = RROWS * RXP; // 16-byte chunks per plane (2691)
 constexpr int NTHR = 32 * TYP;      // one thread = one x-pair x two y-pairs
 constexpr int NWAVE = NTHR / 64;
 constexpr int KCH = (NCHUNK + NTHR - 1) / NTHR;  // chunks per thread (6)
-constexpr int XBLOCKS = 2 * ((RROWS + 7) / 8);   // 8-row x 32-pair blocks of the x lifting (10)
-constexpr int XB2 = XBLOCKS - NWAVE;             // blocks left for a second round (2)
-static_assert(XB2 >= 0 && XB2 <= NWAVE, "x-lifting blocks: at most two rounds");
+// x lifting: a lane takes XPL adjacent x-pairs of one staged row, so that rows x lane groups fill the workgroup in ONE
+// round: 39 rows x 13 groups of 5 pairs = 507 tasks on 512 lanes (with four pairs per lane the 39 x 16 tasks took two
+// rounds on two of the eight waves while the other six waited at the barrier)
+constexpr int XPL = (RROWS * TXP + NTHR - 1) / NTHR;   // x-pairs per lane (5)
+constexpr int XG = (TXP + XPL - 1) / XPL;              // lane groups per row (13)
+static_assert(RROWS * XG <= NTHR, "x lifting: one round");
+static_assert(XG * XPL + 4 <= RXP, "x lifting: the last group's chunks stay inside the row pitch");
 constexpr size_t LDS_BYTES = (size_t)2 * NCHUNK * 16 + (size_t)RROWS * XLP * 8;
 
 // blockIdx.x -> (tile column, tile row).  Workgroups are dealt round-robin over the 8 XCDs (b % 8 says which
@@ -124,19 +128,20 @@ __device__ inline void lift_fwd_two(const double s[6], const double d[5], double
     lo1 = s2d * WR_ZETA; hi1 = d2d * WR_IZETA;
 }
 
-// forward lifting of four adjacent pairs from s[-2..5], d[-2..4]: 22 lifting steps, 5.5 per pair (the same expression tree
-// per output as lift_fwd_two and as the reference's line loop: the outputs are bit-identical)
-__device__ inline void lift_fwd_four(const double s[8], const double d[7], double lo[4], double hi[4])
+// forward lifting of N adjacent pairs from s[-2..N+1], d[-2..N]: 4 N + 6 lifting steps (N = 5: 5.2 per pair; the same
+// expression tree per output as lift_fwd_two and as the reference's line loop: the outputs are bit-identical)
+template <int N>
+__device__ inline void lift_fwd_n(const double s[N + 4], const double d[N + 3], double lo[N], double hi[N])
 {
-    double d1[7], s1[7], d2[6];
+    double d1[N + 3], s1[N + 3], d2[N + 2];
 #pragma unroll
-    for (int k = 0; k < 7; k++) d1[k] = d[k] + WR_ALPHA * (s[k + 1] + s[k]);
+    for (int k = 0; k < N + 3; k++) d1[k] = d[k] + WR_ALPHA * (s[k + 1] + s[k]);
 #pragma unroll
-    for (int k = 1; k < 7; k++) s1[k] = s[k] + WR_BETA * (d1[k] + d1[k - 1]);
+    for (int k = 1; k < N + 3; k++) s1[k] = s[k] + WR_BETA * (d1[k] + d1[k - 1]);
 #pragma unroll
-    for (int k = 1; k < 6; k++) d2[k] = d1[k] + WR_GAMMA * (s1[k + 1] + s1[k]);
+    for (int k = 1; k < N + 2; k++) d2[k] = d1[k] + WR_GAMMA * (s1[k + 1] + s1[k]);
 #pragma unroll
-    for (int k = 2; k < 6; k++) {
+    for (int k = 2; k < N + 2; k++) {
         const double s2 = s1[k] + WR_DELTA * (d2[k] + d2[k - 1]);
         lo[k - 2] = s2 * WR_ZETA;
         hi[k - 2] = d2[k] * WR_IZETA;
@@ -212,56 +217,52 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
     const int iL = m1 - 1 - px0;  // local index of the last x-pair of the domain (right-edge tiles)
 
-    // x lifting of every staged row of plane p -> xl.  Wave w owns rows 2(w + NWAVE k) and the next.
-    // First the mirrored x halo of those rows is patched (edge tiles only), THEN all rows are
-    // read: with no LDS store between the reads of consecutive rows the compiler can issue the
-    // next row's ds_read_b128s while the current row's lifting chain is still executing.
+    // x lifting of every staged row of plane p -> xl.  Thread tid takes row tid / XG, pairs XPL * (tid % XG) and the
+    // following (the last group of a row is one pair short).  First the mirrored x halo of the rows this wave reads is
+    // patched (edge tiles only; a row two waves share gets the same values from both), THEN the row is read.
+    const int xrow = tid / XG, xg = tid - xrow * XG;
+    const bool xact = xrow < RROWS;
+    const int wrow0 = (w << 6) / XG;  // first staged row this wave reads
     auto xlift = [&](int p) {
         double2* rp = raw + p * NCHUNK;
         if (left_edge | right_edge) {
             // whole-sample mirror of the x halo, in pair terms: pair -1 = (s[1], d[0]),
             // pair -2 = (s[2], d[1]); pair m = (s[m-1], d[m-2]), pair m+1 = (s[m-2], d[m-3]).
-            // Wave w patches the rows it reads below: the row blocks w and (w < XB2 ? NWAVE + w : none).
-            if (lane < 32) {
-                const int blk = (lane < 16) ? w : (w < XB2 ? NWAVE + w : -1);
-                const int row = (blk >> 1) * 8 + ((lane >> 1) & 7);
-                if (blk >= 0 && row < RROWS) {
-                    double2* e = rp + row * RXP;
-                    if (left_edge) e[lane & 1] = (lane & 1) ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
-                    if (right_edge) {
-                        double2* f = e + iL + 3 + (lane & 1);
-                        f[0] = (lane & 1) ? make_double2(f[-3].x, f[-4].y) : make_double2(f[-1].x, f[-2].y);
-                    }
+            const int row = wrow0 + (lane >> 1);
+            if (lane < 2 * ((63 + XG) / XG + 1) && row < RROWS && row <= ((w << 6) + 63) / XG) {
+                double2* e = rp + row * RXP;
+                if (left_edge) e[lane & 1] = (lane & 1) ? make_double2(e[3].x, e[2].y) : make_double2(e[4].x, e[3].y);
+                if (right_edge) {
+                    double2* f = e + iL + 3 + (lane & 1);
+                    f[0] = (lane & 1) ? make_double2(f[-3].x, f[-4].y) : make_double2(f[-1].x, f[-2].y);
                 }
             }
         }
-        // Four adjacent x-pairs per lane: 22 lifting steps where two lanes with two pairs each need 28, and 8 chunk reads
-        // where they need 12.  A wave takes a block of 8 rows x 8 lane columns (32 x-pairs = half the tile's width): lane =
-        // 8 * column + row, so that the 8 lanes an LDS instruction serves together differ in the ROW (see RXP / XLP).
-        // 39 rows x 2 halves = 10 blocks: block w for every wave, blocks 8 and 9 for waves 0 and 1.
-        const int lrow = lane & 7, lcol = lane >> 3;
-        auto block = [&](int blk) {
-            const int row = (blk >> 1) * 8 + lrow;
-            if (row >= RROWS) return;
-            const int jq = ((blk & 1) * 8 + lcol) * 4;  // first of this lane's four x-pairs
-            const double2* r = rp + row * RXP + jq;
-            const double2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4], v5 = r[5], v6 = r[6], v7 = r[7];
-            if (MM_IN) {  // v2 .. v5 are this lane's own pairs: all lanes and rows together cover every sample read
-                in_lo = fmin(fmin(fmin(in_lo, v2.x), fmin(v2.y, fmin(v3.x, v3.y))), fmin(fmin(v4.x, v4.y), fmin(v5.x, v5.y)));
-                in_hi = fmax(fmax(fmax(in_hi, v2.x), fmax(v2.y, fmax(v3.x, v3.y))), fmax(fmax(v4.x, v4.y), fmax(v5.x, v5.y)));
+        if (!xact) return;
+        const int jq = xg * XPL;  // first of this lane's x-pairs; its chunks: jq .. jq + XPL + 3 (lane stride 80 bytes: the
+                                  // eight lanes a ds_read_b128 serves together hit eight different quarters of the banks)
+        const double2* r = rp + xrow * RXP + jq;
+        double2 v[XPL + 4];
+#pragma unroll
+        for (int k = 0; k < XPL + 4; k++) v[k] = r[k];
+        if (MM_IN) {  // v[2 .. XPL + 1] are this lane's own pairs (the last group's last one is its neighbour's: still a
+                      // sample of the level input, like every halo value): all lanes together cover every sample read
+#pragma unroll
+            for (int k = 2; k < XPL + 2; k++) {
+                in_lo = fmin(in_lo, fmin(v[k].x, v[k].y));
+                in_hi = fmax(in_hi, fmax(v[k].x, v[k].y));
             }
-            const double sv[8] = {v0.x, v1.x, v2.x, v3.x, v4.x, v5.x, v6.x, v7.x};
-            const double dv[7] = {v0.y, v1.y, v2.y, v3.y, v4.y, v5.y, v6.y};
-            double lo[4], hi[4];
-            lift_fwd_four(sv, dv, lo, hi);
-            double* o = xl + row * XLP + jq;
-            *reinterpret_cast<double2*>(o) = make_double2(lo[0], lo[1]);
-            *reinterpret_cast<double2*>(o + 2) = make_double2(lo[2], lo[3]);
-            *reinterpret_cast<double2*>(o + TXP) = make_double2(hi[0], hi[1]);
-            *reinterpret_cast<double2*>(o + TXP + 2) = make_double2(hi[2], hi[3]);
-        };
-        block(w);
-        if (w < XB2) block(NWAVE + w);
+        }
+        double sv[XPL + 4], dv[XPL + 3], lo[XPL], hi[XPL];
+#pragma unroll
+        for (int k = 0; k < XPL + 4; k++) sv[k] = v[k].x;
+#pragma unroll
+        for (int k = 0; k < XPL + 3; k++) dv[k] = v[k].y;
+        lift_fwd_n<XPL>(sv, dv, lo, hi);
+        double* o = xl + xrow * XLP + jq;
+#pragma unroll
+        for (int k = 0; k < XPL; k++)
+            if (k < TXP - (XG - 1) * XPL || xg < XG - 1) { o[k] = lo[k]; o[TXP + k] = hi[k]; }
     };
     // y lifting of this thread's two y-pairs (2w, 2w+1) for its two x columns:
     // out[4*yp + {0,1,2,3}] = {LL, HL, LH, HH} of y-pair yp
@@ -382,13 +383,19 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
 // Inverse level (waveletcdf97_3d.c:281-466): z, then y, then x.
 //   * the coefficient planes of z-pair t (low-z plane t, high-z plane q3+t; per plane the four
 //     xy quadrants LL/HL/LH/HH of the tile + 2 halo pairs on every side, i.e. 4 x 20 x 68
-//     doubles) stream global -> LDS; halo ROWS are mirrored by choosing the source row;
+//     doubles) go from global memory straight into registers; halo ROWS are mirrored by choosing
+//     the source row;
 //   * z: pointwise streaming register pipeline on every staged point (tile + halo), 4 doubles
-//     of state per point; the even output plane goes to LDS, the odd one waits in registers;
+//     of state per point; both output planes of the pair go to LDS;
 //   * y: each wave rebuilds the 4 output rows of its two y-pairs for all 136 coefficient
 //     columns by recomputation from 11 rows (wave-private LDS rows, no workgroup barrier);
 //   * x: mirrored halo COLUMNS are patched in those rows (x mirroring commutes with the
-//     pointwise z and y steps), then every lane rebuilds one x-pair per row and stores 16 B.
+//     pointwise z and y steps), then every lane rebuilds FOUR adjacent x-pairs of one of the four
+//     rows (22 lifting steps where two lanes with two pairs each need 28) and stores 4 x 16 B.
+// The scaling that opens every 1-D inverse pass (s * 1/zeta, d * zeta, waveletcdf97_3d.c:312-313) is applied where a
+// value is PRODUCED for the next pass -- by the z step for the y pass, by the y pass for the x pass -- instead of where
+// it is consumed: the same single multiplication of the same operands, so the same bits, but once per value and not
+// once per lane that re-reads it (a value is read by 5.5 lanes of the next pass on average).
 // =====================================================================================
 namespace {
 #ifndef WR_ITYP
@@ -401,8 +408,18 @@ constexpr int HX = TXP + 4;              // coefficient columns per quadrant row
 constexpr int HY = ITYP + 4;              // coefficient rows per quadrant (20)
 constexpr int CROW = HX / 2;             // 16-byte chunks per row (34)
 constexpr int NCI = 4 * HY * CROW;       // chunks per plane (2720)
-constexpr int KCI = (NCI + INTHR - 1) / INTHR;  // chunk slots per thread (6)
-constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * 2 * (2 * HX) * 8;
+// A thread's chunk slots: the first KH cover the y-low quadrants (LL, HL), the last KH the y-high ones (LH, HH), so
+// that the scale a slot's values leave the z step with is a compile-time constant
+constexpr int NCH = 2 * HY * CROW;       // chunks per y-half (1360)
+constexpr int KH = (NCH + INTHR - 1) / INTHR;   // chunk slots per thread and half (3)
+constexpr int KCI = 2 * KH;              // chunk slots per thread (6)
+// Wave-private rows between the y and the x stage: 4 rows of [xlow 68 | xhigh 68].  The 8 lanes a ds_read_b128 serves
+// together are 4 rows x 2 lane columns (32 bytes apart); with rows 9 x 128 bytes apart and shifted by {0, 1, 4, 5}
+// 16-byte pieces their reads fall into eight different quarters of the 32 banks.
+constexpr int YPITCH = 144;              // doubles between rows
+constexpr int YWAVE = 4 * YPITCH + 16;   // doubles per wave
+__device__ inline int yrow_off(int r) { return r * YPITCH + (r & 1) * 2 + (r >> 1) * 8; }
+constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * YWAVE * 8;
 
 // whole-sample symmetric extension in coefficient space (even length 2M):
 //   low-pass  s[-k] = s[k],    s[M-1+k] = s[M-k]
@@ -410,14 +427,10 @@ constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * 2 * (2 * HX) 
 __device__ inline int mirror_s(int k, int M) { if (k < 0) k = -k; if (k >= M) k = 2 * M - 1 - k; return k < 0 ? 0 : (k >= M ? M - 1 : k); }
 __device__ inline int mirror_d(int k, int M) { if (k < 0) k = -k - 1; if (k >= M) k = 2 * M - 2 - k; return k < 0 ? 0 : (k >= M ? M - 1 : k); }
 
-// inverse lifting of two adjacent pairs from s[-1..3], d[-2..3] (unscaled inputs)  (:312-337): 14 lifting steps
-__device__ inline void lift_inv_two(const double sr[5], const double dr[6], double out[4])
+// inverse lifting of two adjacent pairs from s[-1..3], d[-2..3], both already scaled (s * 1/zeta, d * zeta)  (:314-337):
+// 14 lifting steps
+__device__ inline void lift_inv_two(const double s[5], const double d[6], double out[4])
 {
-    double s[5], d[6];
-#pragma unroll
-    for (int k = 0; k < 5; k++) s[k] = sr[k] * WR_IZETA;
-#pragma unroll
-    for (int k = 0; k < 6; k++) d[k] = dr[k] * WR_ZETA;
     double s1[5], d1[4], s2[3];
 #pragma unroll
     for (int k = 0; k < 5; k++) s1[k] = s[k] - WR_DELTA * (d[k + 1] + d[k]);
@@ -429,6 +442,24 @@ __device__ inline void lift_inv_two(const double sr[5], const double dr[6], doub
     out[1] = d1[1] - WR_ALPHA * (s2[1] + s2[0]);
     out[2] = s2[1];
     out[3] = d1[2] - WR_ALPHA * (s2[2] + s2[1]);
+}
+
+// inverse lifting of four adjacent pairs from s[-1..5], d[-2..5] (scaled): 22 lifting steps, 5.5 per pair; every output
+// is the expression tree of lift_inv_two and of the reference's line loop
+__device__ inline void lift_inv_four(const double s[7], const double d[8], double ev[4], double od[4])
+{
+    double s1[7], d1[6], s2[5];
+#pragma unroll
+    for (int k = 0; k < 7; k++) s1[k] = s[k] - WR_DELTA * (d[k + 1] + d[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) d1[k] = d[k + 1] - WR_GAMMA * (s1[k + 1] + s1[k]);
+#pragma unroll
+    for (int k = 0; k < 5; k++) s2[k] = s1[k + 1] - WR_BETA * (d1[k + 1] + d1[k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ev[k] = s2[k];
+        od[k] = d1[k + 1] - WR_ALPHA * (s2[k + 1] + s2[k]);
+    }
 }
 }  // namespace
 
@@ -447,7 +478,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 #endif
     extern __shared__ double2 lds2[];
     double2* zb = lds2;                   // [2][NCI]   the two z-reconstructed planes of a step
-    double* yb = reinterpret_cast<double*>(lds2 + 2 * NCI);  // [INWAVE][2][2*HX] wave-private rows
+    double* yb = reinterpret_cast<double*>(lds2 + 2 * NCI);  // [INWAVE][YWAVE] wave-private rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + TXP - 1) / TXP;
@@ -458,12 +489,16 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
 
-    // source offsets of this thread's chunk slots inside a z-plane
-    int offL[KCI], offH[KCI];
-    unsigned lll_mask = 0;
+    // source offsets of this thread's chunk slots inside a z-plane; zi: where the slot's chunk lives in a zb plane
+    int offL[KCI], offH[KCI], zi[KCI];
+    unsigned lll_mask = 0, valid_mask = 0;
 #pragma unroll
     for (int k = 0; k < KCI; k++) {
-        const int c = tid + INTHR * k;
+        const int half = k / KH;                       // 0: y-low quadrants, 1: y-high quadrants
+        const int ch = tid + INTHR * (k - half * KH);  // chunk inside the half
+        const int c = half * NCH + (ch < NCH ? ch : 0);
+        if (ch < NCH) valid_mask |= 1u << k;
+        zi[k] = c;
         const int q = c / (HY * CROW), rem = c - q * (HY * CROW);
         const int row = rem / CROW, cc = rem - row * CROW;
         const int gyp = (q & 2) ? mirror_d(py0 - 2 + row, m2) : mirror_s(py0 - 2 + row, m2);
@@ -477,13 +512,13 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     // the coefficient chunks of z-pair t go straight into registers: the z step is the only reader,
     // it runs first in a step, and the registers are free again for the next pair right after it
     double2 rl[KCI], rh[KCI];
-    auto fetch = [&](int t, int, int) {
+    auto fetch = [&](int t) {
         const double* pl = src + (size_t)t * s_sz;
         const double* pll = low + (size_t)t * l_sz;
         const double* ph = src + (size_t)(m3 + t) * s_sz;
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
-            if (tid + INTHR * k < NCI) {
+            if ((valid_mask >> k) & 1) {
                 rl[k] = *reinterpret_cast<const double2*>((((lll_mask >> k) & 1) ? pll : pl) + offL[k]);
                 rh[k] = *reinterpret_cast<const double2*>(ph + offH[k]);
             }
@@ -492,69 +527,82 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
     const int iL = m1 - 1 - px0;
-    double* ybw = yb + w * (2 * 2 * HX);  // this wave's two rows of [xlow 68 | xhigh 68]
-    const int J = 2 * w;                   // first of this wave's two local y-pairs
+    double* ybw = yb + w * YWAVE;  // this wave's four rows of [xlow 68 | xhigh 68] (yrow_off)
+    const int J = 2 * w;           // first of this wave's two local y-pairs
 
-    // x stage on the wave's two staged rows: patch mirrored halo columns, rebuild, store
+    // x stage on the wave's four staged rows (scaled by the y stage): patch mirrored halo columns, rebuild, store
     auto xstage = [&](int zplane, int yrow0) {
-        if (left_edge && lane < 4) {
-            double* r = ybw + (lane >> 1) * (2 * HX);
-            if (lane & 1) { r[0] = r[4]; r[1] = r[3]; }              // s[-2] = s[2], s[-1] = s[1]
-            else { r[HX + 0] = r[HX + 3]; r[HX + 1] = r[HX + 2]; }   // d[-2] = d[1], d[-1] = d[0]
-        }
-        if (right_edge && lane < 4) {
-            double* r = ybw + (lane >> 1) * (2 * HX);
-            if (lane & 1) { r[iL + 3] = r[iL + 2]; r[iL + 4] = r[iL + 1]; }            // s[m] = s[m-1], s[m+1] = s[m-2]
-            else { r[HX + iL + 3] = r[HX + iL + 1]; r[HX + iL + 4] = r[HX + iL]; }     // d[m] = d[m-2], d[m+1] = d[m-3]
-        }
-        {   // two adjacent x-pairs per lane (14 lifting steps instead of 20): lanes 0-31 take the
-            // first of the two rows, lanes 32-63 the second
-            const int r = lane >> 5, i = (lane & 31) * 2;
-            const double* row = ybw + r * (2 * HX);
-            // local column of pair k is k + 2:  s[i-1..i+3] -> i+1..i+5,  d[i-2..i+3] -> i..i+5
-            const double sr[5] = {row[i + 1], row[i + 2], row[i + 3], row[i + 4], row[i + 5]};
-            const double dr[6] = {row[HX + i], row[HX + i + 1], row[HX + i + 2], row[HX + i + 3], row[HX + i + 4],
-                                  row[HX + i + 5]};
-            double o[4];
-            lift_inv_two(sr, dr, o);
-            const int y = yrow0 + r;
-            double* dstp = out + (size_t)zplane * o_sz + (size_t)y * o_sy + 2 * (px0 + i);
-            if (y < n2) {
-                if (px0 + i < m1) *reinterpret_cast<double2*>(dstp) = make_double2(o[0], o[1]);
-                if (px0 + i + 1 < m1) *reinterpret_cast<double2*>(dstp + 2) = make_double2(o[2], o[3]);
+        if ((left_edge | right_edge) && lane < 8) {
+            double* r = ybw + yrow_off(lane >> 1);
+            if (left_edge) {
+                if (lane & 1) { r[0] = r[4]; r[1] = r[3]; }              // s[-2] = s[2], s[-1] = s[1]
+                else { r[HX + 0] = r[HX + 3]; r[HX + 1] = r[HX + 2]; }   // d[-2] = d[1], d[-1] = d[0]
             }
+            if (right_edge) {
+                if (lane & 1) { r[iL + 3] = r[iL + 2]; r[iL + 4] = r[iL + 1]; }            // s[m] = s[m-1], s[m+1] = s[m-2]
+                else { r[HX + iL + 3] = r[HX + iL + 1]; r[HX + iL + 4] = r[HX + iL]; }     // d[m] = d[m-2], d[m+1] = d[m-3]
+            }
+        }
+        // four adjacent x-pairs per lane: lane = 4 * (lane column) + row
+        const int r = lane & 3, i = (lane >> 2) * 4;
+        const double* row = ybw + yrow_off(r);
+        // local column of pair k is k + 2:  s[i-1..i+5] -> i+1..i+7,  d[i-2..i+5] -> i..i+7
+        const double2* ps = reinterpret_cast<const double2*>(row + i);
+        const double2* pd = reinterpret_cast<const double2*>(row + HX + i);
+        const double2 s0 = ps[0], s1 = ps[1], s2 = ps[2], s3 = ps[3];
+        const double2 d0 = pd[0], d1 = pd[1], d2 = pd[2], d3 = pd[3];
+        const double sv[7] = {s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y};
+        const double dv[8] = {d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
+        double ev[4], od[4];
+        lift_inv_four(sv, dv, ev, od);
+        // The lane's eight results are 64 consecutive bytes of its row: stored as they are, every store instruction would
+        // write 16 bytes out of every 64.  They go back to the wave's rows instead (everything has been read: LDS runs a
+        // wave's instructions in order) and leave row by row, one x-pair per lane: 1 KB of consecutive bytes per instruction.
+        double* o = ybw + yrow_off(r) + 2 * i;
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<double2*>(o + 2 * k) = make_double2(ev[k], od[k]);
+        const bool own = px0 + lane < m1;
+        double* dstp = out + (size_t)zplane * o_sz + (size_t)yrow0 * o_sy + 2 * (px0 + lane);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const double2 v = *reinterpret_cast<const double2*>(ybw + yrow_off(rr) + 2 * lane);
+            if (own && yrow0 + rr < n2) *reinterpret_cast<double2*>(dstp + (size_t)rr * o_sy) = v;
         }
     };
-    // y + x stages of the z-plane held in zb
-    auto yxstage = [&](int zplane, const double2* zbuf) {
-        double keep[3][2];
+    // y pass of one coefficient column cid of the z-plane in zbuf (scaled by the z step): the wave's four output rows,
+    // scaled for the x pass
+    auto ycolumn = [&](const double2* zbuf, int cid, double o[4]) {
+        const int xh = cid >= HX;             // 0: x-low column, 1: x-high column
+        const int col = cid - xh * HX;
+        const double* zl = reinterpret_cast<const double*>(zbuf) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
+        const double* zh = reinterpret_cast<const double*>(zbuf) + (size_t)(2 + xh) * (HY * HX) + col;    // y-high quadrant
+        // local row of y-pair k is k + 2:  s[J-1..J+3] -> rows J+1..J+5,  d[J-2..J+3] -> rows J..J+5
+        const double sr[5] = {zl[(J + 1) * HX], zl[(J + 2) * HX], zl[(J + 3) * HX], zl[(J + 4) * HX], zl[(J + 5) * HX]};
+        const double dr[6] = {zh[(J + 0) * HX], zh[(J + 1) * HX], zh[(J + 2) * HX], zh[(J + 3) * HX], zh[(J + 4) * HX],
+                              zh[(J + 5) * HX]};
+        lift_inv_two(sr, dr, o);
+        const double sc = xh ? WR_ZETA : WR_IZETA;  // the x pass's opening scale (x-low columns are its s, x-high its d)
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
-            const int cid = lane + 64 * p;
-            if (cid < 2 * HX) {
-                const int xh = cid >= HX;             // 0: x-low column, 1: x-high column
-                const int col = cid - xh * HX;
-                const double* zl = reinterpret_cast<const double*>(zbuf) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
-                const double* zh = reinterpret_cast<const double*>(zbuf) + (size_t)(2 + xh) * (HY * HX) + col;    // y-high quadrant
-                // local row of y-pair k is k + 2:  s[J-1..J+3] -> rows J+1..J+5,  d[J-2..J+3] -> rows J..J+5
-                const double sr[5] = {zl[(J + 1) * HX], zl[(J + 2) * HX], zl[(J + 3) * HX], zl[(J + 4) * HX], zl[(J + 5) * HX]};
-                const double dr[6] = {zh[(J + 0) * HX], zh[(J + 1) * HX], zh[(J + 2) * HX], zh[(J + 3) * HX], zh[(J + 4) * HX],
-                                      zh[(J + 5) * HX]};
-                double o[4];
-                lift_inv_two(sr, dr, o);
-                ybw[cid] = o[0];
-                ybw[2 * HX + cid] = o[1];
-                keep[p][0] = o[2];
-                keep[p][1] = o[3];
-            }
+        for (int r = 0; r < 4; r++) o[r] *= sc;
+    };
+    // The 136 columns are two full passes of the wave and YT = 8 columns more: those of BOTH planes of the z-pair share
+    // one pass (lanes 0..7 the even plane, 8..15 the odd one), five passes per z-pair instead of six.
+    constexpr int YT = 2 * HX - 128;
+    static_assert(YT > 0 && (YT & (YT - 1)) == 0 && 2 * YT <= 64, "y stage: the leftover columns of two planes fit one pass");
+    // y + x stages of the z-plane held in zbuf; tail: this lane's leftover column (mine: of this plane)
+    auto yxstage = [&](int zplane, const double2* zbuf, const double tail[4], bool mine) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            double o[4];
+            ycolumn(zbuf, lane + 64 * p, o);
+#pragma unroll
+            for (int r = 0; r < 4; r++) ybw[yrow_off(r) + lane + 64 * p] = o[r];
+        }
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) ybw[yrow_off(r) + 128 + (lane & (YT - 1))] = tail[r];
         }
         xstage(zplane, 2 * (py0 + J));
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            const int cid = lane + 64 * p;
-            if (cid < 2 * HX) { ybw[cid] = keep[p][0]; ybw[2 * HX + cid] = keep[p][1]; }
-        }
-        xstage(zplane, 2 * (py0 + J) + 2);
     };
 
     // z pipeline state per staged point: 2 points per chunk slot
@@ -564,7 +612,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 #pragma unroll
         for (int e = 0; e < 2; e++) dprev[k][e] = s1prev[k][e] = d1prev[k][e] = s2prev[k][e] = 0.0;
 
-    if (tb < m3) fetch(tb, 0, KCI);
+    if (tb < m3) fetch(tb);
     for (int t = tb; t <= te; t++) {
         const int j = t - 2;
         const bool emit = j >= z0 && j < z1;  // block-uniform
@@ -577,14 +625,15 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         // ---- z step on every staged point  (waveletcdf97_3d.c:312-337 along z)
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
-            const int c = tid + INTHR * k;
-            if (c < NCI) {
+            if ((valid_mask >> k) & 1) {
                 // Boundary forms by mirroring: c * (v + v) has the bits of (2 c) * v, so "the missing neighbour
                 // is the other one" replaces the reference's second expression (waveletcdf97_3d.c:316,323,
                 // 329,335) with one block-uniform select on an operand.  Steps outside [0, m3) of the
                 // pipeline's fill and drain compute on stale operands; nothing they produce reaches an
                 // emitted plane (the selects below cut exactly those dependencies).
                 const double lo[2] = {rl[k].x, rl[k].y}, hi[2] = {rh[k].x, rh[k].y};
+                // the y pass's opening scale: y-low quadrants are its s (* 1/zeta), y-high quadrants its d (* zeta)
+                const double sc = (k < KH) ? WR_IZETA : WR_ZETA;
                 double ev[2], od[2];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
@@ -593,21 +642,23 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                     const double S1 = s0 - WR_DELTA * (d0 + (first ? d0 : dprev[k][e]));
                     const double D1 = dprev[k][e] - WR_GAMMA * ((last1 ? s1prev[k][e] : S1) + s1prev[k][e]);
                     const double S2 = s1prev[k][e] - WR_BETA * (D1 + (first1 ? D1 : d1prev[k][e]));
-                    ev[e] = s2prev[k][e];
-                    od[e] = d1prev[k][e] - WR_ALPHA * ((last2 ? s2prev[k][e] : S2) + s2prev[k][e]);
+                    ev[e] = s2prev[k][e] * sc;
+                    od[e] = (d1prev[k][e] - WR_ALPHA * ((last2 ? s2prev[k][e] : S2) + s2prev[k][e])) * sc;
                     dprev[k][e] = d0; s1prev[k][e] = S1; d1prev[k][e] = D1; s2prev[k][e] = S2;
                 }
-                if (emit) { zb[c] = make_double2(ev[0], ev[1]); zb[NCI + c] = make_double2(od[0], od[1]); }
+                if (emit) { zb[zi[k]] = make_double2(ev[0], ev[1]); zb[NCI + zi[k]] = make_double2(od[0], od[1]); }
             }
         }
         STAMP(2);
-        if (t + 1 <= te && t + 1 < m3) fetch(t + 1, 0, KCI);  // in flight behind the y/x stages
+        if (t + 1 <= te && t + 1 < m3) fetch(t + 1);  // in flight behind the y/x stages
         STAMP(3);
         lds_barrier();  // both planes complete
         STAMP(6);
         if (emit) {
-            yxstage(2 * j, zb);
-            yxstage(2 * j + 1, zb + NCI);
+            double tail[4] = {0.0, 0.0, 0.0, 0.0};
+            if (lane < 2 * YT) ycolumn(zb + (lane >= YT ? NCI : 0), 128 + (lane & (YT - 1)), tail);
+            yxstage(2 * j, zb, tail, lane < YT);
+            yxstage(2 * j + 1, zb + NCI, tail, lane >= YT && lane < 2 * YT);
             STAMP(4);
         }
     }

@@ -59,6 +59,23 @@ inline PlaneRef plane_ref(const uint8_t* base)  // a plane that is one array
 void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval,
                     const PlaneRef& q, bool write_resid, double* partial, double* result, hipStream_t st);
 
+// ---- the same plane without a residual array (k_quant_blk): x holds the COEFFICIENTS and stays as it is; the residual this
+// plane is cut from is recomputed from them and the scalars of the planes before (prev, in order); want_minmax: result[0..1]
+// = min/max of the residual after this plane; write_resid: x := that residual (the last plane of a caller who wants it);
+// hist != nullptr: the per-60000-symbol-block byte histograms of the plane (block_histograms' output) are written too.
+// quantize_plane_blk_ok: the pointers are 16-byte aligned (and WR_QUANT_INPLACE is not set).
+constexpr int kQuantPrevMax = 7;
+struct QuantPrev {
+    int n = 0;
+    double aopt[kQuantPrevMax], bopt[kQuantPrevMax], deps[kQuantPrevMax], minval[kQuantPrevMax];
+    void push(double a, double b, double d, double m) { aopt[n] = a; bopt[n] = b; deps[n] = d; minval[n] = m; n++; }
+};
+bool quantize_plane_blk_ok(const double* x, const PlaneRef& q);
+void quantize_plane_blk(double* x, size_t n, const QuantPrev& prev, double aopt, double bopt, double deps, double minval, const PlaneRef& q,
+                        bool write_resid, bool want_minmax, uint16_t* hist, double* partial, double* result, hipStream_t st);
+// x := the residual after the planes in prev
+void residual_apply(double* x, size_t n, const QuantPrev& prev, hipStream_t st);
+
 // ---- quantizer plane with the non-uniform (local) cutoff mask (wrappers.cpp:343-379, 397-398):
 // loops over PHYSICAL positions, maps each to its wavelet-space index (ind_p2w_3d,
 // waveletcdf97_3d.c:473-553) and quantizes there; coefficients of the finest level whose plane

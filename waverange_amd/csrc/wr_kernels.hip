@@ -508,6 +508,179 @@ void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, 
     if (write_resid) hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g1 + g2, result);
 }
 
+// =====================================================================================
+// Quantizer plane WITHOUT a residual array: the residual a plane is cut from is recomputed from the coefficient array.
+// The reference keeps the residual in memory (wrappers.cpp:397-398: fld_1d[j] -= iqfld*deps + minval after every plane), 17 B
+// per element and plane here: 8 read, 8 written, 1 of plane.  But the residual after plane l is a fixed expression of the
+// coefficient and of the scalars of planes 0 .. l, so a lane that holds the coefficient can redo the subtractions of the
+// planes before (7 instructions each) instead of reading what the pass before wrote: 9 B per element and plane (8 read, 1
+// of plane), whatever the plane, and the same bits -- every residual is produced by the same operations on the same
+// operands, a register instead of a store and a load between them.  The array is written once, by the last plane, and only
+// if the caller wants the residual (encoding_wrap leaves it in fld_1d).
+// One workgroup works through whole coding blocks (60000 symbols, wrappers.cpp:68: the host coder's model blocks), so it
+// also leaves the block's byte histogram (k_hist's job: one pass over the plane less); within a block, 4096 elements at a
+// time, the plane bytes staged through LDS for 16-byte stores as in k_quant_lds.
+// =====================================================================================
+constexpr int QB = 60000;
+template <bool WRITE, bool MM, bool HIST>
+__global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict__ x, size_t n, QuantPrev prev, double aopt, double bopt,
+                                                              double deps, double minval, PlaneRef q, uint16_t* __restrict__ hist,
+                                                              double* __restrict__ partial)
+{
+    constexpr int COPIES = 8;
+    __shared__ unsigned int h[HIST ? COPIES : 1][256 + 1];  // +1: the copies start in different banks
+    __shared__ uchar2 sq[Q_CHUNK / 2];
+    const double nan = __builtin_nan("");
+    double lo = nan, hi = nan;
+    const int t = threadIdx.x;
+    unsigned int* const mine = h[HIST ? (t & (COPIES - 1)) : 0];
+    const size_t nb = n / QB + 1;  // includes the (possibly empty) final block, as the host coder's block count does
+    for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const size_t b0 = b * QB, b1 = (b0 + QB < n) ? b0 + QB : n;
+        if (HIST) {
+#pragma unroll
+            for (int c = 0; c < COPIES; c++) h[c][t] = 0;  // (ordered against the adds by the barrier behind the sq stores)
+        }
+        // a block may straddle two chunks of the plane (never more); 60000 b and the chunk size are multiples of 16, so a
+        // 16-byte piece lies in one of them
+        const size_t c0 = (b0 < n ? b0 : (n ? n - 1 : 0)) >> q.shift, edge = (c0 + 1) << q.shift;
+        uint8_t* const p0 = q.chunk[c0] + (b0 - (c0 << q.shift));
+        uint8_t* const p1 = edge < b1 ? q.chunk[c0 + 1] : p0;
+        for (size_t g0 = b0; g0 < b1; g0 += Q_CHUNK) {
+            const bool full = g0 + Q_CHUNK <= b1;  // workgroup-uniform
+            double2* const x2 = reinterpret_cast<double2*>(x + g0);
+            double2 v[Q_CHUNK / 512];
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < Q_CHUNK / 512; j++) v[j] = x2[j * 256 + t];
+            } else {
+#pragma unroll
+                for (int j = 0; j < Q_CHUNK / 512; j++) {
+                    const size_t e = g0 + 2 * (size_t)(j * 256 + t);
+                    v[j] = make_double2(0.0, 0.0);
+                    if (e + 1 < b1) v[j] = x2[j * 256 + t];
+                    else if (e < b1) v[j].x = x[e];
+                }
+            }
+            // the planes before this one, in order: v becomes the residual this plane is cut from
+#pragma unroll
+            for (int p = 0; p < kQuantPrevMax; p++) {
+                if (p < prev.n) {
+                    const double pa = prev.aopt[p], pb = prev.bopt[p], pd = prev.deps[p], pm = prev.minval[p];
+#pragma unroll
+                    for (int j = 0; j < Q_CHUNK / 512; j++) {
+                        const unsigned char qa = (unsigned char)(int)(pa * v[j].x + pb);
+                        const unsigned char qb = (unsigned char)(int)(pa * v[j].y + pb);
+                        v[j].x = v[j].x - ((double)qa * pd + pm);
+                        v[j].y = v[j].y - ((double)qb * pd + pm);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < Q_CHUNK / 512; j++) {
+                // (unsigned char)(double): C truncation toward zero of a value in [0.5, 255.5]
+                const unsigned char qa = (unsigned char)(int)(aopt * v[j].x + bopt);
+                const unsigned char qb = (unsigned char)(int)(aopt * v[j].y + bopt);
+                sq[j * 256 + t] = make_uchar2(qa, qb);
+                if (WRITE || MM) {
+                    v[j].x = v[j].x - ((double)qa * deps + minval);
+                    v[j].y = v[j].y - ((double)qb * deps + minval);
+                    if (full) {
+                        if (WRITE) x2[j * 256 + t] = v[j];
+                        if (MM) { mm_acc(v[j].x, lo, hi); mm_acc(v[j].y, lo, hi); }
+                    } else {
+                        const size_t e = g0 + 2 * (size_t)(j * 256 + t);
+                        if (e + 1 < b1) {
+                            if (WRITE) x2[j * 256 + t] = v[j];
+                            if (MM) { mm_acc(v[j].x, lo, hi); mm_acc(v[j].y, lo, hi); }
+                        } else if (e < b1) {
+                            if (WRITE) x[e] = v[j].x;
+                            if (MM) mm_acc(v[j].x, lo, hi);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const size_t i = g0 + 16 * (size_t)t;  // this lane's 16 symbols
+            if (i < b1) {
+                const uint4 w = reinterpret_cast<const uint4*>(sq)[t];
+                uint8_t* const dstq = i < edge ? p0 + (i - b0) : p1 + (i - edge);
+                const int cnt = (b1 - i < 16) ? (int)(b1 - i) : 16;
+                const unsigned int words[4] = {w.x, w.y, w.z, w.w};
+                if (cnt == 16) *reinterpret_cast<uint4*>(dstq) = w;
+                else
+                    for (int k = 0; k < cnt; k++) dstq[k] = (uint8_t)(words[k >> 2] >> (8 * (k & 3)));
+                if (HIST) {  // a run of equal symbols is one add (bit planes of a smooth field are dominated by one value)
+                    unsigned int prevs = words[0] & 0xff, run = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const unsigned int sb = (words[k >> 2] >> (8 * (k & 3))) & 0xff;
+                        if (k < cnt) {
+                            if (sb != prevs) { atomicAdd(&mine[prevs], run); prevs = sb; run = 0; }
+                            run++;
+                        }
+                    }
+                    atomicAdd(&mine[prevs], run);
+                }
+            }
+            __syncthreads();
+        }
+        if (HIST) {
+            unsigned int tot = 0;
+#pragma unroll
+            for (int c = 0; c < COPIES; c++) tot += h[c][t];
+            hist[b * 256 + t] = (uint16_t)tot;
+            __syncthreads();  // before the next block zeroes the bins
+        }
+    }
+    if (MM) block_minmax(lo, hi, partial);
+}
+
+// x := the residual after the planes in `prev` (the rare paths that want the residual in memory between two planes)
+__global__ __launch_bounds__(WR_RED_THREADS) void k_resid_apply(double* __restrict__ x, size_t n, QuantPrev prev)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = x[i];
+#pragma unroll
+        for (int p = 0; p < kQuantPrevMax; p++)
+            if (p < prev.n) {
+                const unsigned char qa = (unsigned char)(int)(prev.aopt[p] * v + prev.bopt[p]);
+                v = v - ((double)qa * prev.deps[p] + prev.minval[p]);
+            }
+        x[i] = v;
+    }
+}
+
+void residual_apply(double* x, size_t n, const QuantPrev& prev, hipStream_t st)
+{
+    if (!prev.n || !n) return;
+    hipLaunchKernelGGL(k_resid_apply, dim3(red_grid(n, 1)), dim3(WR_RED_THREADS), 0, st, x, n, prev);
+}
+
+bool quantize_plane_blk_ok(const double* x, const PlaneRef& q)
+{
+    static const bool on = !(getenv("WR_QUANT_INPLACE") && atoi(getenv("WR_QUANT_INPLACE")));
+    return on && (((uintptr_t)x | (uintptr_t)q.chunk[0]) & 15) == 0;
+}
+
+void quantize_plane_blk(double* x, size_t n, const QuantPrev& prev, double aopt, double bopt, double deps, double minval, const PlaneRef& q,
+                        bool write_resid, bool want_minmax, uint16_t* hist, double* partial, double* result, hipStream_t st)
+{
+    const size_t nb = n / QB + 1;
+    // one round of resident workgroups (8 per CU at most), each with a dozen blocks or more to stream through
+    const int g = (int)(nb < (size_t)WR_RED_BLOCKS / 2 ? nb : (size_t)WR_RED_BLOCKS / 2);
+#define WR_QB_LAUNCH(W, M, H) hipLaunchKernelGGL((k_quant_blk<W, M, H>), dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, prev, aopt, bopt, deps, minval, q, hist, partial)
+    if (hist) {
+        if (write_resid) { if (want_minmax) WR_QB_LAUNCH(true, true, true); else WR_QB_LAUNCH(true, false, true); }
+        else { if (want_minmax) WR_QB_LAUNCH(false, true, true); else WR_QB_LAUNCH(false, false, true); }
+    } else {
+        if (write_resid) { if (want_minmax) WR_QB_LAUNCH(true, true, false); else WR_QB_LAUNCH(true, false, false); }
+        else { if (want_minmax) WR_QB_LAUNCH(false, true, false); else WR_QB_LAUNCH(false, false, false); }
+    }
+#undef WR_QB_LAUNCH
+    if (want_minmax) hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(WR_RED_THREADS), 0, st, partial, g, result);
+}
+
 // local-cutoff variant: one thread per physical position (a bijection onto wavelet space)
 __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_local(double* __restrict__ x, size_t n, double aopt,
                                                                 double bopt, double deps, double minval,
