@@ -445,9 +445,26 @@ def main():
         if rank == 0:
             print("bench.py: --gpus not given, following the launcher's WORLD_SIZE=%d" % world, file=sys.stderr)
     if args.dry_launch:
+        # what this rank would take of the host if the node had one GPU per rank (no GPU is touched: the node's GPUs' NUMA
+        # nodes are not looked up, the share is the rank's slice of whole cores; HBM assumed empty): the rehearsal of an
+        # N-rank run's sizing on a box with fewer GPUs
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        sizing = None
+        try:
+            mine = cpu_share_of(local_rank, local_world, read_cpu_topology(()))
+            if mine:
+                os.sched_setaffinity(0, mine)
+            jobs, sizing = fit_jobs(args.jobs, len(tols), n ** 3 * 8, int(0.97 * 288e9), len(mine) if mine else None, host_mode,
+                                    pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=local_world, nslots=args.slots or 3,
+                                    planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
+            sizing.update(lanes=jobs * len(tols), cpu_affinity_share=len(mine) if mine else None,
+                          cpus=",".join("%d" % c for c in sorted(os.sched_getaffinity(0))) if len(os.sched_getaffinity(0)) <= 64 else "%d CPUs" % len(os.sched_getaffinity(0)))
+        except (OSError, ValueError) as e:
+            sizing = {"error": str(e)}
         print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
-                          "launched_by": "bench.py" if os.environ.get("WR_BENCH_CHILD") else "external launcher" if world > 1 else "none"}), flush=True)
+                          "launched_by": "bench.py" if os.environ.get("WR_BENCH_CHILD") else "external launcher" if world > 1 else "none",
+                          "sizing": sizing}), flush=True)
         return
 
     import torch
@@ -493,14 +510,20 @@ def main():
     # How many fields in flight this rank can afford (fit_jobs): its share of the CPUs, of the host memory (coded
     # streams) and the free HBM (the quantized planes of the fields in flight live there).  --jobs is the upper bound.
     share = None
+    gpus_on_node = ndev
     if backend == "nccl":
         bdfs = []
         for d in range(ndev):
             pr = torch.cuda.get_device_properties(d)
             bdfs.append("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
         share = take_cpu_share(local_rank, ndev, bdfs)
+    elif world > ndev:
+        # rehearsal (gloo, ranks share devices): the host is split as if the node had one GPU per rank, so that the
+        # ranks' CPU shares, lanes and memory shares are the ones of the real run
+        gpus_on_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        share = take_cpu_share(local_rank, gpus_on_node, ())
     jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
-                            pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=ndev, nslots=args.slots or 3,
+                            pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=gpus_on_node, nslots=args.slots or 3,
                             planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
     limits["cpu_affinity_share"] = share
 
@@ -818,10 +841,16 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": "3-D CDF-9/7 transform, 4 levels (mean of forward and inverse), all launches",
                          "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3)},
-            # the other kernel groups: algorithmic bytes per element 17 L - 8 (quantizer, L planes), L + 8
-            # (dequantise-accumulate), 8 per min/max pass (two passes per encode); times from HIP events in the run
+            # the other kernel groups: algorithmic bytes per element L + 8 (dequantise-accumulate), 8 per min/max
+            # pass (two passes per encode); times from HIP events in the run.  Quantizer: SURVEY.md 8d counts the reference's
+            # formulation, 17 L - 8 (the residual array read and rewritten by every plane but the last); the kernels here cut
+            # every plane from a residual recomputed from the coefficient array (k_quant_blk), so what a plane MUST move is 8
+            # bytes read + 1 written: 9 L, and that is what the fraction is priced on (block histograms ride along)
             "roofline_groups": {"forward_transform": group(alg_bytes, fwd_ms), "inverse_transform": group(alg_bytes, inv_ms),
-                                "quantizer": group((17.0 * L - 8.0) * nelem, mean(acc["quant_ms"])),
+                                "quantizer": dict(group(9.0 * L * nelem, mean(acc["quant_ms"])),
+                                                  in_place_formulation_bytes=(17.0 * L - 8.0) * nelem,
+                                                  note="planes cut from residuals recomputed from the coefficients: 9 B per element and plane instead of the "
+                                                       "in-place formulation's 17 (SURVEY.md 8d); block histograms included"),
                                 "dequantizer": group((L + 8.0) * nelem, mean(acc["dequant_ms"])),
                                 "minmax_x2": group(2 * nbytes_field, mean(acc["minmax_ms"])) if mean(acc["minmax_ms"]) > 1e-3
                                 else {"fused_into": "forward_transform", "note": "both reductions ride on the forward kernels' loads and stores; their 16 B/elem are not counted in its algorithmic bytes"},

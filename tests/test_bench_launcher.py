@@ -24,6 +24,8 @@ def test_gpus_flag_starts_that_many_ranks():
     assert sorted(l["rank"] for l in lines) == [0, 1]
     assert all(l["world_size"] == 2 and l["launched_by"] == "bench.py" and l["master"].startswith("127.0.0.1:") for l in lines)
     assert len({l["master"] for l in lines}) == 1
+    # every rank also says what it would take of the host (lanes, CPUs, host-memory share): the rehearsal of an N-rank sizing
+    assert all(l["sizing"]["lanes"] >= 2 and "cpus_per_rank" in l["sizing"] and "host_mem_per_rank_gib" in l["sizing"] for l in lines)
 
 
 def test_under_an_external_launcher_it_is_one_rank():

@@ -537,9 +537,11 @@ from oracle.loader import Oracle
 api.set_verbosity(0)
 o = Oracle()
 with api.Context(0) as c:
-    for shape, tol in (((130, 70, 34), 1e-10), ((128, 64, 80), 1e-16), ((200, 120, 72), 1e-6), ((37, 21, 13), 1e-9), ((61, 1, 1), 1e-7)):
+    for shape, tol in (((130, 70, 34), 1e-10), ((128, 64, 80), 1e-16), ((200, 120, 72), 1e-6), ((37, 21, 13), 1e-9), ((61, 1, 1), 1e-7),
+                       ((128, 128, 256), 1e-6), ((64, 64, 144), 1e-4)):
         f = synth.field(*shape, seed=99)
         want = o.encode(f, tol)
+        rec_want = o.decode(want, f.shape)
         for keep in (True, False):
             buf = c.to_device(f)
             c.set_keep_residual(keep)
@@ -553,19 +555,27 @@ with api.Context(0) as c:
         # host entry point (block histograms from the quantizer, planes through the windows)
         enc, _ = c.encode_host(f, tol)
         assert np.array_equal(enc["data"], want["data"]), (shape, tol, "host entry point")
+        # and back: the inverse transform takes up to four planes as they are (its finest level dequantizes on the way)
+        out = np.empty_like(f); enc["data"] = enc["data"].copy()
+        c.decode_host(out, enc)
+        assert bits_equal(out, rec_want), (shape, tol, "reconstruction")
 print("ok")
 '''
 
 
-@pytest.mark.parametrize("env", [{}, {"WR_TEST_ZERO_MIN_PATH": "1"}, {"WR_QUANT_INPLACE": "1"}, {"WR_PLANE_CHUNK_MB": "1"}],
-                         ids=["recompute", "rare_path_after_every_plane", "in_place", "chunked_planes"])
+@pytest.mark.parametrize("env", [{}, {"WR_TEST_ZERO_MIN_PATH": "1", "WR_INV_DQ": "1"}, {"WR_QUANT_INPLACE": "1"}, {"WR_PLANE_CHUNK_MB": "1", "WR_INV_DQ": "1"}],
+                         ids=["recompute", "rare_path_after_every_plane+inverse_from_planes", "in_place", "chunked_planes+inverse_from_planes"])
 def test_quantizer_without_a_residual_array(env, tmp_path):
     """The quantizer planes are cut from residuals that are recomputed from the coefficient array (k_quant_blk: 9 instead of
     17 bytes per element and plane), with the block histograms written on the way; the reference updates the array in place
     after every plane (wrappers.cpp:397-398).  Same header scalars, coded bytes and final residual as the oracle -- for up to
     eight planes, odd sizes (tails of coding blocks and of 16-byte pieces), planes in 1 MiB chunks (blocks that straddle
     two), with the residual wanted and not; when the rare path that needs the residual in memory between two planes is taken
-    after EVERY plane (sign of a zero minimum: residual_apply, then in place); and with the in-place kernels alone."""
+    after EVERY plane (sign of a zero minimum: residual_apply, then in place); and with the in-place kernels alone.
+    The way back likewise, with the accumulate pass (the default) and with WR_INV_DQ=1: the inverse transform's finest level
+    dequantizes its detail octants from the planes (up to four; k_inv_fused<true>, wrappers.cpp:513-514 in registers) --
+    planes as one array and in chunks, shapes whose z-planes divide a chunk and shapes that fall back to the accumulate
+    pass: reconstruction == oracle."""
     import os, subprocess, sys
     from util import ROOT
     script = tmp_path / "quant_paths.py"

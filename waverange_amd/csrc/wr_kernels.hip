@@ -522,43 +522,49 @@ void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, 
 // time, the plane bytes staged through LDS for 16-byte stores as in k_quant_lds.
 // =====================================================================================
 constexpr int QB = 60000;
+constexpr int QW = 1024;  // elements a wave takes at a time: 8 x 16-byte loads per lane, 16 plane bytes per lane
 template <bool WRITE, bool MM, bool HIST>
 __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict__ x, size_t n, QuantPrev prev, double aopt, double bopt,
                                                               double deps, double minval, PlaneRef q, uint16_t* __restrict__ hist,
                                                               double* __restrict__ partial)
 {
     constexpr int COPIES = 8;
+    constexpr int NW = WR_RED_THREADS / 64;
     __shared__ unsigned int h[HIST ? COPIES : 1][256 + 1];  // +1: the copies start in different banks
-    __shared__ uchar2 sq[Q_CHUNK / 2];
+    // wave-private staging of the plane bytes: written as byte pairs, read back as 16-byte pieces by the same wave (LDS runs
+    // a wave's instructions in order), so the waves of a workgroup never wait for one another inside a coding block
+    __shared__ uchar2 sq[NW][QW / 2];
     const double nan = __builtin_nan("");
     double lo = nan, hi = nan;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     unsigned int* const mine = h[HIST ? (t & (COPIES - 1)) : 0];
     const size_t nb = n / QB + 1;  // includes the (possibly empty) final block, as the host coder's block count does
     for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const size_t b0 = b * QB, b1 = (b0 + QB < n) ? b0 + QB : n;
         if (HIST) {
 #pragma unroll
-            for (int c = 0; c < COPIES; c++) h[c][t] = 0;  // (ordered against the adds by the barrier behind the sq stores)
+            for (int c = 0; c < COPIES; c++) h[c][t] = 0;
+            __syncthreads();
         }
         // a block may straddle two chunks of the plane (never more); 60000 b and the chunk size are multiples of 16, so a
         // 16-byte piece lies in one of them
         const size_t c0 = (b0 < n ? b0 : (n ? n - 1 : 0)) >> q.shift, edge = (c0 + 1) << q.shift;
         uint8_t* const p0 = q.chunk[c0] + (b0 - (c0 << q.shift));
         uint8_t* const p1 = edge < b1 ? q.chunk[c0 + 1] : p0;
-        for (size_t g0 = b0; g0 < b1; g0 += Q_CHUNK) {
-            const bool full = g0 + Q_CHUNK <= b1;  // workgroup-uniform
+        for (size_t g0 = b0 + (size_t)w * QW; g0 < b1; g0 += (size_t)NW * QW) {
+            const bool full = g0 + QW <= b1;  // wave-uniform
             double2* const x2 = reinterpret_cast<double2*>(x + g0);
-            double2 v[Q_CHUNK / 512];
+            double2 v[QW / 128];
             if (full) {
 #pragma unroll
-                for (int j = 0; j < Q_CHUNK / 512; j++) v[j] = x2[j * 256 + t];
+                for (int j = 0; j < QW / 128; j++) v[j] = x2[j * 64 + lane];
             } else {
 #pragma unroll
-                for (int j = 0; j < Q_CHUNK / 512; j++) {
-                    const size_t e = g0 + 2 * (size_t)(j * 256 + t);
+                for (int j = 0; j < QW / 128; j++) {
+                    const size_t e = g0 + 2 * (size_t)(j * 64 + lane);
                     v[j] = make_double2(0.0, 0.0);
-                    if (e + 1 < b1) v[j] = x2[j * 256 + t];
+                    if (e + 1 < b1) v[j] = x2[j * 64 + lane];
                     else if (e < b1) v[j].x = x[e];
                 }
             }
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict
                 if (p < prev.n) {
                     const double pa = prev.aopt[p], pb = prev.bopt[p], pd = prev.deps[p], pm = prev.minval[p];
 #pragma unroll
-                    for (int j = 0; j < Q_CHUNK / 512; j++) {
+                    for (int j = 0; j < QW / 128; j++) {
                         const unsigned char qa = (unsigned char)(int)(pa * v[j].x + pb);
                         const unsigned char qb = (unsigned char)(int)(pa * v[j].y + pb);
                         v[j].x = v[j].x - ((double)qa * pd + pm);
@@ -577,21 +583,21 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict
                 }
             }
 #pragma unroll
-            for (int j = 0; j < Q_CHUNK / 512; j++) {
+            for (int j = 0; j < QW / 128; j++) {
                 // (unsigned char)(double): C truncation toward zero of a value in [0.5, 255.5]
                 const unsigned char qa = (unsigned char)(int)(aopt * v[j].x + bopt);
                 const unsigned char qb = (unsigned char)(int)(aopt * v[j].y + bopt);
-                sq[j * 256 + t] = make_uchar2(qa, qb);
+                sq[w][j * 64 + lane] = make_uchar2(qa, qb);
                 if (WRITE || MM) {
                     v[j].x = v[j].x - ((double)qa * deps + minval);
                     v[j].y = v[j].y - ((double)qb * deps + minval);
                     if (full) {
-                        if (WRITE) x2[j * 256 + t] = v[j];
+                        if (WRITE) x2[j * 64 + lane] = v[j];
                         if (MM) { mm_acc(v[j].x, lo, hi); mm_acc(v[j].y, lo, hi); }
                     } else {
-                        const size_t e = g0 + 2 * (size_t)(j * 256 + t);
+                        const size_t e = g0 + 2 * (size_t)(j * 64 + lane);
                         if (e + 1 < b1) {
-                            if (WRITE) x2[j * 256 + t] = v[j];
+                            if (WRITE) x2[j * 64 + lane] = v[j];
                             if (MM) { mm_acc(v[j].x, lo, hi); mm_acc(v[j].y, lo, hi); }
                         } else if (e < b1) {
                             if (WRITE) x[e] = v[j].x;
@@ -600,14 +606,13 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict
                     }
                 }
             }
-            __syncthreads();
-            const size_t i = g0 + 16 * (size_t)t;  // this lane's 16 symbols
+            const size_t i = g0 + 16 * (size_t)lane;  // this lane's 16 symbols
+            const uint4 wq = reinterpret_cast<const uint4*>(&sq[w][0])[lane];
             if (i < b1) {
-                const uint4 w = reinterpret_cast<const uint4*>(sq)[t];
                 uint8_t* const dstq = i < edge ? p0 + (i - b0) : p1 + (i - edge);
                 const int cnt = (b1 - i < 16) ? (int)(b1 - i) : 16;
-                const unsigned int words[4] = {w.x, w.y, w.z, w.w};
-                if (cnt == 16) *reinterpret_cast<uint4*>(dstq) = w;
+                const unsigned int words[4] = {wq.x, wq.y, wq.z, wq.w};
+                if (cnt == 16) *reinterpret_cast<uint4*>(dstq) = wq;
                 else
                     for (int k = 0; k < cnt; k++) dstq[k] = (uint8_t)(words[k >> 2] >> (8 * (k & 3)));
                 if (HIST) {  // a run of equal symbols is one add (bit planes of a smooth field are dominated by one value)
@@ -623,9 +628,9 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict
                     atomicAdd(&mine[prevs], run);
                 }
             }
-            __syncthreads();
         }
         if (HIST) {
+            __syncthreads();
             unsigned int tot = 0;
 #pragma unroll
             for (int c = 0; c < COPIES; c++) tot += h[c][t];
@@ -760,31 +765,33 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_dequant(double* __restrict__
 // reads each plane's 4 KB with 16-byte loads, and every store instruction of a wave then covers
 // 1 KB of consecutive doubles (the direct form above moves 2 bytes per lane and load).
 constexpr int DQ_CHUNK = 4096;
+constexpr int DQW = 1024;  // elements a wave takes at a time; the staging is wave-private (no workgroup barrier: LDS runs a
+                           // wave's instructions in order), so the waves of a workgroup stream independently
 __global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, size_t nchunks, DequantParams p)
 {
-    __shared__ uint4 sq[8][DQ_CHUNK / 16];
-    const int t = threadIdx.x;
-    for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const size_t base = ch * DQ_CHUNK;
+    __shared__ uint4 sq[4][8][DQW / 16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t nsub = nchunks * (DQ_CHUNK / DQW);
+    for (size_t sc = (size_t)blockIdx.x * 4 + w; sc < nsub; sc += (size_t)gridDim.x * 4) {
+        const size_t base = sc * DQW;
 #pragma unroll
         for (int l = 0; l < 8; l++)
-            if (l < p.nlay) sq[l][t] = reinterpret_cast<const uint4*>(p.q[l].at(base))[t];
-        __syncthreads();
+            if (l < p.nlay) sq[w][l][lane] = reinterpret_cast<const uint4*>(p.q[l].at(base))[lane];
         double2* a2 = reinterpret_cast<double2*>(acc + base);
 #pragma unroll
-        for (int j = 0; j < DQ_CHUNK / 512; j++) {
+        for (int j = 0; j < DQW / 128; j++) {
             double2 a = make_double2(0.0, 0.0);
 #pragma unroll
             for (int l = 0; l < 8; l++) {
                 if (l < p.nlay) {
-                    const uchar2 qq = reinterpret_cast<const uchar2*>(&sq[l][0])[j * 256 + t];
+                    const uchar2 qq = reinterpret_cast<const uchar2*>(&sq[w][l][0])[j * 64 + lane];
                     a.x = a.x + ((double)qq.x * p.deps[l] + p.minval[l]);
                     a.y = a.y + ((double)qq.y * p.deps[l] + p.minval[l]);
                 }
             }
-            a2[j * 256 + t] = a;
+            a2[j * 64 + lane] = a;
         }
-        __syncthreads();
     }
 }
 

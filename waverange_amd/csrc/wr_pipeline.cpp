@@ -635,10 +635,13 @@ int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int n
     const size_t n = (size_t)nx * ny * nz;
     const bool fused = wlev == 4 && use_fused(nx, ny, nz, -4);
     if (fused) if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
+    // (the finest level of the fused inverse can dequantize its detail octants on the way: then only the coarse corner box
+    // is accumulated, inside transform_inv_fused, and the time between ev_a and ev_b is zero)
+    const bool from_planes = fused && wrk::inv_dq_ok(p, nx, ny, nz);
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
+    if (!from_planes) wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    if (fused) wrk::transform_inv_fused(s->scratch, d_fld, s->lowbuf, nx, ny, nz, c->stream);
+    if (fused) wrk::transform_inv_fused(s->scratch, d_fld, s->lowbuf, nx, ny, nz, c->stream, from_planes ? &p : nullptr);
     else wrk::transform(d_fld, s->scratch, nx, ny, nz, -wlev, c->stream);
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     return WR_OK;
