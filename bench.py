@@ -355,7 +355,9 @@ def cpu_baseline(size, tols, ncores):
             "sample": "%d^3 fp64 field of the same generator, tols %s, encode+decode, %.1f s"
                       % (size, ",".join("%g" % t for t in tols), dt),
             "all_cores": {"value": round(mb_all / dt_all, 2), "unit": "MB/s", "cores": ncores,
-                          "sample": "one %d^3 field per core on %d cores at once, same tols, %.1f s" % (size_all, ncores, dt_all)}}
+                          "sample": "one %d^3 field per core on %d cores at once, same tols, %.1f s" % (size_all, ncores, dt_all)},
+            "note": "bounded samples, smaller than the workload's 1024^3: the reference's rate falls with the field size (BASELINE.md: 440 -> 233 MB/s forward "
+                    "from 256^3 to 512^3), so both figures are upper bounds for what it does at size"}
 
 
 def launch_ranks(nranks, argv, dry):

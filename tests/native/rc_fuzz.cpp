@@ -30,6 +30,37 @@ int main() {
             (void)wrrc::decode_plane(bad.data(), bad.size(), dst.data(), n);
         }
     }
+    // four noise planes in one loop: the hand-allotted form of the byte-aligned decoder loop (decode_symbols_noise4_asm), also
+    // with one stream of the four damaged or cut short
+    for (int round = 0; round < 3; round++) {
+        const size_t n = (size_t)60000 * (5 + round) + 1234 * round;
+        const int count = 4;
+        std::vector<std::vector<uint8_t>> p(count), enc(count), back(count);
+        std::vector<const uint8_t*> ip(count);
+        std::vector<uint8_t*> bp(count);
+        std::vector<size_t> len(count), got(count);
+        for (int k = 0; k < count; k++) {
+            p[k].resize(n); enc[k].resize(wrrc::encode_bound(n)); back[k].resize(n);
+            for (size_t i = 0; i < n; i++) { const unsigned r = rnd(); p[k][i] = (uint8_t)(round == 2 ? (r & 255) : ((r & 255) < (r >> 8 & 255) ? (r & 255) : (r >> 8 & 255))); }
+            len[k] = wrrc::encode_plane(p[k].data(), n, enc[k].data(), nullptr);
+            enc[k].resize(len[k]); enc[k].shrink_to_fit();
+            ip[k] = enc[k].data(); bp[k] = back[k].data();
+        }
+        wrrc::decode_planes(count, ip.data(), len.data(), bp.data(), n, got.data());
+        for (int k = 0; k < count; k++)
+            if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("four noise planes: decode failed round=%d k=%d\n", round, k); return 1; }
+        for (int trial = 0; trial < 4; trial++) {
+            const int victim = (int)(rnd() % count);
+            std::vector<uint8_t> bad(enc[victim]);
+            if (trial < 2) bad.resize(bad.size() * (trial + 1) / 3);
+            else for (int j = 0; j < 64; j++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
+            std::vector<const uint8_t*> ip2(ip); std::vector<size_t> l2(len);
+            ip2[victim] = bad.data(); l2[victim] = bad.size();
+            wrrc::decode_planes(count, ip2.data(), l2.data(), bp.data(), n, got.data());
+            for (int k = 0; k < count; k++)
+                if (k != victim && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("four noise planes: healthy stream disturbed by a damaged one\n"); return 1; }
+        }
+    }
     // several planes interleaved in one loop (encode_planes / decode_planes): same bytes as one by one,
     // streams long enough for the unchecked fast loop (needs 3 * 60000 + 8 unread bytes per stream)
     for (size_t n : {(size_t)7, (size_t)60000 * 2, (size_t)60000 * 9 + 17}) for (int count = 1; count <= 6; count++) {

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The scalar decoder loop on noise planes (7.5 bits per symbol: no dominant symbols, no usable bucket table), 1-4 streams
 interleaved on one thread: the loop a third of the pool's worker-seconds goes to.  WR_RC_NOISE_LOOP=0 selects the general
-loop (two stream bytes and a 7-bit shift per renormalisation step) instead of the byte-aligned one.  CPU only.
+loop (two stream bytes and a 7-bit shift per renormalisation step) instead of the byte-aligned one, WR_RC_NOISE_ASM=0 the
+compiler's register allocation instead of the hand-written four-stream loop.  CPU only.
 usage: rc_noise.py [blocks per plane]"""
 import os
 import sys
@@ -13,11 +14,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from waverange_amd import api
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+kmax = 4
 n = 60000 * nb
 rs = np.random.RandomState(1)
-planes = [np.minimum(rs.randint(0, 256, n), rs.randint(64, 320, n)).astype(np.uint8) for _ in range(4)]
+planes = [np.minimum(rs.randint(0, 256, n), rs.randint(64, 320, n)).astype(np.uint8) for _ in range(kmax)]
 streams = api.range_encode_multi(planes)
-for k in (1, 2, 3, 4):
+for k in range(1, kmax + 1):
     best = 1e9
     for _ in range(3):
         t = time.time()
@@ -25,4 +27,5 @@ for k in (1, 2, 3, 4):
         best = min(best, time.time() - t)
     assert all(np.array_equal(o, p) for o, p in zip(out, planes[:k]))
     print("noise planes, %d stream(s) in the loop: decode %6.1f Msym/s per thread (%5.1f per stream)  [WR_RC_NOISE_LOOP=%s]"
-          % (k, k * n / best / 1e6, n / best / 1e6, os.environ.get("WR_RC_NOISE_LOOP", "1")), flush=True)
+          % (k, k * n / best / 1e6, n / best / 1e6, os.environ.get("WR_RC_NOISE_LOOP", "1")) +
+          (" [WR_RC_NOISE_ASM=0]" if os.environ.get("WR_RC_NOISE_ASM") == "0" else ""), flush=True)

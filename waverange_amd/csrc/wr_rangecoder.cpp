@@ -959,6 +959,115 @@ void decode_symbols_noise(Dec* const* ds, uint8_t* const* dst, const BlockModel*
     }
     for (int k = 0; k < NS; k++) { ds[k]->low = low2[k] >> 1; ds[k]->range = range[k]; ds[k]->pos = (size_t)(p[k] - ds[k]->in); ds[k]->held = p[k][-1]; }
 }
+#if defined(__x86_64__) && defined(__GNUC__)
+// The four-stream form of the loop above with the registers allotted by hand.  Four streams carry 4 x {state, range,
+// stream pointer} + the loop counter = 13 live values besides the temporaries, two of which the division fixes (eax,
+// edx): the compiler keeps the states in registers and passes all four RANGES through the stack in every iteration
+// (a store and a forwarded load on each stream's dependency chain) -- 45 instructions per symbol.  Here states and
+// ranges own eight registers, the stream pointers live in memory (they are only read, and bumped by `adc $0, mem`: a
+// pointer is needed again a whole iteration later), models and output pointers are loaded where they are used: 32
+// instructions per symbol, nothing of the chain on the stack.  Same arithmetic, step by step, as decode_symbols_noise.
+// EPYC 9575F, one thread, four noise streams: 437 against 423 Msym/s (profiles/r04/m_*): the loop is bound by neither its
+// chains nor its instruction count alone -- five to eight streams with state and range packed into one register each (37
+// instructions per symbol, built and measured, not kept) reach 440 / 467 / 478 / 469 Msym/s per thread at 88 .. 59 per stream,
+// and six streams to a loop in the pool 14.9 against 15.2 GB/s on the same box (n_bench_k8_dec*.json).
+struct NoiseCtx {
+    const uint8_t* q[4];
+    const BlockModel* mod[4];
+    uint8_t* sym[4];
+};
+#define WR_NOISE_STREAM(K, L2, RG)                                                                          \
+    "movq   " #K "*8(%[ctx]), %%rsi\n\t"                                                                     \
+    "movzbl (%%rsi), %%esi\n\t"                                                                              \
+    "movl   %" L2 ", %%eax\n\t"                                                                              \
+    "shll   $8, %%eax\n\t"                                                                                   \
+    "orl    %%esi, %%eax\n\t"                                                                                \
+    "movl   %" RG ", %%edx\n\t"                                                                              \
+    "shll   $8, %%edx\n\t"                                                                                   \
+    "cmpl   $0x800001, %" RG "\n\t"                                                                          \
+    "cmovbl %%eax, %" L2 "\n\t"                                                                              \
+    "cmovbl %%edx, %" RG "\n\t"                                                                              \
+    "adcq   $0, " #K "*8(%[ctx])\n\t"                                                                        \
+    "cmpl   $0x800000, %" RG "\n\t"                                                                          \
+    "jbe    2" #K "f\n"                                                                                      \
+    "1" #K ":\n\t"                                                                                           \
+    "movl   %" RG ", %%eax\n\t"                                                                              \
+    "imulq  $1172812403, %%rax, %%rcx\n\t" /* range / 60000 by multiply-shift (exact for 32 bits) */         \
+    "shrq   $46, %%rcx\n\t"                                                                                  \
+    "movl   %" L2 ", %%eax\n\t"                                                                              \
+    "shrl   %%eax\n\t"                                                                                       \
+    "xorl   %%edx, %%edx\n\t"                                                                                \
+    "divl   %%ecx\n\t"                                                                                       \
+    "movq   32+" #K "*8(%[ctx]), %%rsi\n\t"                                                                  \
+    "movzbl %c[lk](%%rsi,%%rax), %%eax\n\t"                                                                  \
+    "movl   (%%rsi,%%rax,8), %%edx\n\t"                                                                      \
+    "imull  %%ecx, %%edx\n\t"                                                                                \
+    "cmpl   %%eax, %c[tp](%%rsi)\n\t"                                                                        \
+    "je     3" #K "f\n\t"                                                                                    \
+    "imull  4(%%rsi,%%rax,8), %%ecx\n\t"                                                                     \
+    "movl   %%ecx, %" RG "\n"                                                                                \
+    "4" #K ":\n\t"                                                                                           \
+    "addl   %%edx, %%edx\n\t"                                                                                \
+    "subl   %%edx, %" L2 "\n\t"                                                                              \
+    "movq   64+" #K "*8(%[ctx]), %%rsi\n\t"                                                                  \
+    "movb   %%al, (%%rsi,%[i])\n\t"
+#define WR_NOISE_TAILS(K, L2, RG)                                                                           \
+    "2" #K ":\n\t" /* one byte was not enough (rare): the reference's loop, rangecod.c:294-302 */            \
+    "movq   " #K "*8(%[ctx]), %%rsi\n"                                                                       \
+    "5" #K ":\n\t"                                                                                           \
+    "shll   $8, %" L2 "\n\t"                                                                                 \
+    "movzbl (%%rsi), %%eax\n\t"                                                                              \
+    "orl    %%eax, %" L2 "\n\t"                                                                              \
+    "shll   $8, %" RG "\n\t"                                                                                 \
+    "incq   %%rsi\n\t"                                                                                       \
+    "cmpl   $0x800000, %" RG "\n\t"                                                                          \
+    "jbe    5" #K "b\n\t"                                                                                    \
+    "movq   %%rsi, " #K "*8(%[ctx])\n\t"                                                                     \
+    "jmp    1" #K "b\n"                                                                                      \
+    "3" #K ":\n\t" /* the largest symbol present takes what is left of the range (rangecod.c:345-348) */     \
+    "subl   %%edx, %" RG "\n\t"                                                                              \
+    "jmp    4" #K "b\n"
+void decode_symbols_noise4_asm(Dec* const* ds, uint8_t* const* dst, const BlockModel* const* ms)
+{
+    NoiseCtx ctx;
+    for (int k = 0; k < 4; k++) { ctx.q[k] = ds[k]->in + ds[k]->pos; ctx.mod[k] = ms[k]; ctx.sym[k] = dst[k]; }
+    register uint32_t l0 asm("r8") = (ds[0]->low << 1) | (ds[0]->held & 1u), l1 asm("r9") = (ds[1]->low << 1) | (ds[1]->held & 1u);
+    register uint32_t l2 asm("r10") = (ds[2]->low << 1) | (ds[2]->held & 1u), l3 asm("r11") = (ds[3]->low << 1) | (ds[3]->held & 1u);
+    register uint32_t r0 asm("r12") = ds[0]->range, r1 asm("r13") = ds[1]->range, r2 asm("r14") = ds[2]->range, r3 asm("r15") = ds[3]->range;
+    register uint64_t i asm("rbx") = 0;
+    register NoiseCtx* c asm("rdi") = &ctx;
+    __asm__ volatile(
+        ".p2align 5\n"
+        "9:\n\t"
+        WR_NOISE_STREAM(0, "k[l0]", "k[r0]")
+        WR_NOISE_STREAM(1, "k[l1]", "k[r1]")
+        WR_NOISE_STREAM(2, "k[l2]", "k[r2]")
+        WR_NOISE_STREAM(3, "k[l3]", "k[r3]")
+        "incq   %[i]\n\t"
+        "cmpq   %[n], %[i]\n\t"
+        "jne    9b\n\t"
+        "jmp    8f\n"
+        WR_NOISE_TAILS(0, "k[l0]", "k[r0]")
+        WR_NOISE_TAILS(1, "k[l1]", "k[r1]")
+        WR_NOISE_TAILS(2, "k[l2]", "k[r2]")
+        WR_NOISE_TAILS(3, "k[l3]", "k[r3]")
+        "8:\n"
+        : [l0] "+r"(l0), [l1] "+r"(l1), [l2] "+r"(l2), [l3] "+r"(l3), [r0] "+r"(r0), [r1] "+r"(r1), [r2] "+r"(r2), [r3] "+r"(r3), [i] "+r"(i)
+        : [ctx] "r"(c), [n] "i"((int)kBlock), [lk] "i"(offsetof(BlockModel, lookup)), [tp] "i"(offsetof(BlockModel, top))
+        : "rax", "rcx", "rdx", "rsi", "cc", "memory");
+    const uint32_t lw[4] = {l0, l1, l2, l3}, rg[4] = {r0, r1, r2, r3};
+    for (int k = 0; k < 4; k++) {
+        ds[k]->low = lw[k] >> 1; ds[k]->range = rg[k]; ds[k]->pos = (size_t)(ctx.q[k] - ds[k]->in); ds[k]->held = ctx.q[k][-1];
+    }
+}
+#undef WR_NOISE_STREAM
+#undef WR_NOISE_TAILS
+
+const bool kNoiseAsm = !(getenv("WR_RC_NOISE_ASM") && !atoi(getenv("WR_RC_NOISE_ASM")));
+#else
+const bool kNoiseAsm = false;
+inline void decode_symbols_noise4_asm(Dec* const*, uint8_t* const*, const BlockModel* const*) {}
+#endif
 const bool kNoiseLoop = !(getenv("WR_RC_NOISE_LOOP") && !atoi(getenv("WR_RC_NOISE_LOOP")));
 
 using MultiFn = void (*)(Dec* const*, uint8_t* const*, const BlockModel* const*);
@@ -977,7 +1086,7 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
         case 1: decode_symbols_noise<1>(ds, dst, ms); break;
         case 2: decode_symbols_noise<2>(ds, dst, ms); break;
         case 3: decode_symbols_noise<3>(ds, dst, ms); break;
-        default: decode_symbols_noise<4>(ds, dst, ms); break;
+        default: if (kNoiseAsm) decode_symbols_noise4_asm(ds, dst, ms); else decode_symbols_noise<4>(ds, dst, ms); break;
         }
         return;
     }
@@ -988,10 +1097,6 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
     default: multi_entry<4>(mask, std::make_integer_sequence<unsigned, 16>())(ds, dst, ms); break;
     }
 }
-
-}  // namespace
-
-namespace {
 
 // A decoder stream between two blocks, as it moves from one worker's session to another's.  `d.in` may point into
 // `tail` (the zero-padded copy of the stream's end): moving the vector keeps its buffer where it is.

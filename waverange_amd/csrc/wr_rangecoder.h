@@ -16,7 +16,8 @@ namespace wrrc {
 
 constexpr uint32_t kBlock = 60000;  // reference src/core/defs.h:36
 constexpr int kMaxStreams = 4;      // planes interleaved in one symbol loop by encode_planes / decode_planes
-constexpr int kMaxDecStreams = 4;   // ... by a pool worker's decoder loop (5 and 6 were measured: slower, the loop runs out of registers)
+constexpr int kMaxDecStreams = 4;   // ... by a pool worker's decoder loop (5 and 6 were measured: slower in the compiler's loops, which run out of
+                                    // registers, and no gain in hand-written ones with packed state: profiles/r04/NOTES.md)
 
 // upper bound on the stream length for n symbols
 size_t encode_bound(size_t n);
