@@ -472,7 +472,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             // ---- stage "kernels"
             StageGate gate(pool);
             cu.lock();
-            clock_warmup(c);
+            clock_warmup(c, n);
             rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, hist_buf, info, &local, after_quant, plane_ready, &resid);
             if (hipStreamSynchronize(c->stream) != hipSuccess && rc == WR_OK) rc = fail(WR_ERR_HIP, "the encoder's kernel stage failed on the device" + launch_describe(c));
             if (rc == WR_OK && c->keep_residual && info->nlay && !fld.host && resid != fld.dev) {  // leave the residual where the reference leaves it
@@ -710,7 +710,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
             // ---- stage "kernels"
             StageGate gate(pool);
             StageLock cu(pool->cu_mu);
-            clock_warmup(c);
+            clock_warmup(c, n);
             rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);
             if (rc == WR_OK && hipGetLastError() != hipSuccess) rc = fail(WR_ERR_HIP, "kernel launch failed");
             if (hipStreamSynchronize(c->stream) != hipSuccess && rc == WR_OK) rc = fail(WR_ERR_HIP, "the decoder's kernel stage failed on the device" + launch_describe(c));

@@ -381,7 +381,7 @@ struct StageGate {  // RAII pair of the two: an exception between them must not 
     StageGate(const StageGate&) = delete;
     StageGate& operator=(const StageGate&) = delete;
 };
-void clock_warmup(wr_ctx* c);       // first thing in a host call's kernel stage (cu_mu held)
+void clock_warmup(wr_ctx* c, size_t n);  // first thing in a host call's kernel stage (cu_mu held); n: elements of the field
 int check_dims(int nx, int ny, int nz, const void* dev_ptr);
 
 struct Sem {  // tiny counting semaphore limiting concurrent range-coder threads

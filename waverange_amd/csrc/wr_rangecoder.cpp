@@ -747,9 +747,19 @@ const uint32_t kMixedPct = getenv("WR_RC_MIXED_PCT") ? (uint32_t)atoi(getenv("WR
 // the look-up side of a block model (60 KB + buckets): what the division path needs
 void finish_model_tables(BlockModel& m)
 {
+    uint32_t present = 0, rare = 0;  // rare: symbols of fewer than a bucket's 16 values (they may share a bucket with a neighbour's boundary)
     for (int b = 0; b < 256; b++)
-        if (m.tab[b].sy) memset(m.lookup + m.tab[b].lt, b, m.tab[b].sy);
+        if (m.tab[b].sy) { memset(m.lookup + m.tab[b].lt, b, m.tab[b].sy); present++; rare += m.tab[b].sy < (1u << kBucketShift); }
     memset(m.lookup + m.bs, (int)m.top, kPad);
+    // Two boundaries between symbols of 16 values or more never share a bucket, and a boundary makes its bucket mixed unless
+    // it falls on a multiple of 16: with that many mixed buckets all but certain (noise planes: ~250 symbols of ~235 values
+    // each, 6.8 % of the block; the test asks for 5/4 of the threshold) the table below would be built (3782 entries, ~2 % of
+    // the block's decoding time) only to be switched off.  (Which look-up a block takes never changes what it decodes.)
+    if (present > 2 * rare + 1 && (uint64_t)(present - 2 * rare - 1) * (80u << kBucketShift) >= (uint64_t)m.bs * kMixedPct) {
+        m.use_buckets = false;
+        m.tables_ready = true;
+        return;
+    }
     uint32_t mixed = 0;
     for (uint32_t j = 0; j < kBuckets; j++) {
         const uint32_t lo = j << kBucketShift, hi = lo + (1u << kBucketShift) - 1;
