@@ -515,9 +515,12 @@ def main():
     gpus_on_node = ndev
     if backend == "nccl":
         bdfs = []
-        for d in range(ndev):
-            pr = torch.cuda.get_device_properties(d)
-            bdfs.append("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        try:
+            for d in range(ndev):
+                pr = torch.cuda.get_device_properties(d)
+                bdfs.append("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        except (AttributeError, RuntimeError):
+            bdfs = []  # (no PCI addresses: the shares are slices of all cores instead of the GPUs' own NUMA nodes)
         share = take_cpu_share(local_rank, ndev, bdfs)
     elif world > ndev:
         # rehearsal (gloo, ranks share devices): the host is split as if the node had one GPU per rank, so that the

@@ -673,7 +673,8 @@ void quantize_plane_blk(double* x, size_t n, const QuantPrev& prev, double aopt,
 {
     const size_t nb = n / QB + 1;
     // one round of resident workgroups (8 per CU at most), each with a dozen blocks or more to stream through
-    const int g = (int)(nb < (size_t)WR_RED_BLOCKS / 2 ? nb : (size_t)WR_RED_BLOCKS / 2);
+    static const size_t gmax = []() { const char* e = getenv("WR_QUANT_GRID"); const long v = e ? atol(e) : 0; return v >= 1 && v <= WR_RED_BLOCKS ? (size_t)v : (size_t)WR_RED_BLOCKS / 2; }();
+    const int g = (int)(nb < gmax ? nb : gmax);
 #define WR_QB_LAUNCH(W, M, H) hipLaunchKernelGGL((k_quant_blk<W, M, H>), dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, prev, aopt, bopt, deps, minval, q, hist, partial)
     if (hist) {
         if (write_resid) { if (want_minmax) WR_QB_LAUNCH(true, true, true); else WR_QB_LAUNCH(true, false, true); }
