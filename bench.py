@@ -582,10 +582,35 @@ def main():
     for i in range(len(tols) * jobs):
         ce = ctx if i == 0 else api.Context(dev_index)
         cd = api.Context(dev_index)
-        ln = dict(enc=ce, dec=cd, data=[np.empty(cap, dtype=np.uint8) for _ in range(2)])
+        ln = dict(enc=ce, dec=cd)
         if not host_mode:
             ln["work"], ln["rec"] = ce.alloc(nelem * 8), cd.alloc(nelem * 8)
         lanes.append(ln)
+
+    # The coded streams travel from a lane's encoder to its decoder in hand-over buffers, at most two per lane at a time, each
+    # large enough for any field (setup_wr's bound: virtual memory, only coded bytes are ever touched).  They are not tied to
+    # lanes: a buffer that has held a tight-tolerance field keeps that field's 2 GB resident, so a field takes the buffer its
+    # own tolerance gave back last (a LIFO per tolerance; a new one if there is none) -- the few-hundred-MB streams of the loose
+    # tolerance keep meeting small buffers, and what stays resident is what each tolerance has in flight at a time instead
+    # of 2 GB in every buffer there is.
+    import collections
+    all_bufs = []
+    used_bufs = {}  # tolerance -> deque of idle buffers that held a field of it last
+    buf_lock = threading.Lock()
+
+    def take_buf(tol):
+        with buf_lock:
+            mine = used_bufs.setdefault(tol, collections.deque())
+            if mine:
+                return mine.pop()
+            if len(all_bufs) >= 2 * len(tols) * len(lanes) + 4:
+                raise RuntimeError("bench.py: hand-over buffers leak (two per lane are in flight at most)")
+            all_bufs.append(np.empty(cap, dtype=np.uint8))
+            return all_bufs[-1]
+
+    def give_buf(tol, buf):
+        with buf_lock:
+            used_bufs.setdefault(tol, collections.deque()).append(buf)
 
     # host mode: the reconstructions land in one of a few pinned output fields, borrowed for the device half of a
     # decode only (wr_decode_begin / wr_decode_finish_host); the last reconstruction of the last lane is checked
@@ -658,12 +683,13 @@ def main():
                             coded[k & 1].release()
                             return
                         tol = tols[i % len(tols)]
+                        buf = take_buf(tol)
                         if host_mode:
-                            enc, te = ln["enc"].encode_host(h_in, tol, out=ln["data"][k & 1])
+                            enc, te = ln["enc"].encode_host(h_in, tol, out=buf)
                         else:
                             ln["enc"].copy(ln["work"], orig, nelem * 8)
-                            enc, te = ln["enc"].encode(ln["work"], shape, tol, out=ln["data"][k & 1])
-                        box[k & 1] = (enc, te, tol, i)
+                            enc, te = ln["enc"].encode(ln["work"], shape, tol, out=buf)
+                        box[k & 1] = (enc, te, tol, i, buf)
                         if record and i >= total - len(tols):
                             last_coded[tol] = enc   # its buffer is not written again: no field follows on any lane
                         coded[k & 1].release()
@@ -682,11 +708,15 @@ def main():
                         item = box[k & 1]
                         if item is None or errors:
                             return
-                        enc, te, tol, i = item
+                        enc, te, tol, i, buf = item
+                        # (the last field of every tolerance keeps its buffer out of circulation: parity is taken from it later)
+                        held_back = record and i >= total - len(tols)
                         if host_mode:
                             ln["dec"].decode_begin(shape, enc)       # host range decoding: seconds, no field buffer
-                            if trim_host and not (record and i >= total - len(tols)):
-                                drop_pages(ln["data"][k & 1], enc["ntot_enc"])  # the coded stream is not needed any more: its pages go back
+                            if trim_host and not held_back:
+                                drop_pages(buf, enc["ntot_enc"])  # the coded stream is not needed any more: its pages go back
+                            if not held_back:
+                                give_buf(tol, buf)
                             free[k & 1].release()
                             out = out_pool.get()
                             keep = False
@@ -703,6 +733,8 @@ def main():
                             if record and i == total - 1:
                                 diff, amax = ln["dec"].linf(orig, ln["rec"], nelem)
                                 accuracy["linf_rel"] = diff / amax
+                            if not held_back:
+                                give_buf(tol, buf)
                             free[k & 1].release()
                         k += 1
                         if record:
@@ -910,9 +942,11 @@ def main():
             # BASELINE configs[4]'s tolerance on the same pipeline, outside the timed region: a bounded sample (few lanes, few
             # steps: mostly fill and drain) so that the command stays within minutes; `bench.py --tols 1e-16` is the full run
             try:
-                for ln in lanes:   # the pages of the main run's coded streams go back first: a 1e-16 stream is 6 GB at 1024^3
-                    for buf in ln["data"]:
-                        drop_pages(buf, cap)
+                for buf in all_bufs:   # the pages of the main run's coded streams go back first: a 1e-16 stream is 6 GB at 1024^3
+                    drop_pages(buf, cap)
+                with buf_lock:         # ... and every buffer is in circulation again, for any tolerance (the parity check is done)
+                    used_bufs.clear()
+                    used_bufs[args.secondary_tol] = collections.deque(all_bufs)
                 avail = None
                 with open("/proc/meminfo") as fh:
                     avail = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]
@@ -943,11 +977,11 @@ def main():
             ln = lanes[-1]
             if host_mode:
                 out1 = out_pool.get()
-                enc1, te1 = ln["enc"].encode_host(h_in, tols[-1], out=ln["data"][0])
+                enc1, te1 = ln["enc"].encode_host(h_in, tols[-1], out=take_buf(tols[-1]))
                 td1 = ln["dec"].decode_host(out1, enc1)
             else:
                 ln["enc"].copy(ln["work"], orig, nelem * 8)
-                enc1, te1 = ln["enc"].encode(ln["work"], shape, tols[-1], out=ln["data"][0])
+                enc1, te1 = ln["enc"].encode(ln["work"], shape, tols[-1], out=take_buf(tols[-1]))
                 td1 = ln["dec"].decode(ln["rec"], shape, enc1)
             out["single_field"] = {"tol": tols[-1], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
                                    "decode_s": round(td1["total"], 3),
