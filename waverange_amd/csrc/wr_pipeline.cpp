@@ -714,11 +714,12 @@ void clock_warmup(wr_ctx* c, size_t n)
     static const double ms = []() { const char* e = getenv("WR_CLOCK_WARMUP_MS"); const double v = e ? atof(e) : 40.0; return v < 0 ? 0.0 : (v > 200 ? 200.0 : v); }();
     if (ms <= 0) return;
     DevPool* p = c->pool;
-    // Only where it is free: several calls in flight on this device (a pipeline whose GPU idles between kernel stages: the
-    // burner takes nothing from anybody) and a field large enough for the shader clock to show in its transforms.  A lone
+    // Only where it is free: eight or more calls in flight on this device (a pipeline whose GPU idles between kernel stages:
+    // the burner takes nothing from anybody) and fields of 2 GiB or more (their transforms are milliseconds long; the tools on
+    // 512^3 fields would only see 40 ms more latency per field).  A lone
     // caller would pay tens of milliseconds of latency to save one.  (40 ms: profiles/r04/c_clock_burner_before_the_transform.txt,
     // a forward transform after half a second of idle 4.91 ms, behind 10 / 20 / 40 / 80 ms of load 3.77 / 3.68 / 3.64 / 3.65.)
-    if (p->active_calls.load() < 4 || n < ((size_t)1 << 26)) return;
+    if (p->active_calls.load() < 8 || n < ((size_t)1 << 28)) return;
     if (now() - p->last_stage_end.load() < 0.004) return;  // a stage has just ended: the clock is up
     wrk::burn(ms, 0, 1024, c->d_partial, c->stream);
     (void)hipGetLastError();
