@@ -99,6 +99,13 @@ __device__ inline void tile_of_block(int b, int tiles_x, int tiles_y, int& tx, i
 // the top of the next step (vmcnt(0) + barrier) by every wave that issued it.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// min / max that skip quiet NaNs as fmin / fmax do, as the bare instructions: fmin() / fmax() first canonicalize every operand
+// that comes from memory (a v_max_f64 x, x, x each, to quiet a signalling NaN) -- 72 of the 168 min/max instructions of the
+// encoder's forward kernel.  A signalling NaN in a field is not something the reference's scan survives either (glibc's
+// fmin returns x + y for one); the sign of a zero minimum is settled elsewhere (k_last_zero).
+__device__ inline double vmin64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline double vmax64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __device__ inline int mirror(int v, int n)
 {
     if (v < 0) v = -v;
@@ -250,8 +257,8 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                       // sample of the level input, like every halo value): all lanes together cover every sample read
 #pragma unroll
             for (int k = 2; k < XPL + 2; k++) {
-                in_lo = fmin(in_lo, fmin(v[k].x, v[k].y));
-                in_hi = fmax(in_hi, fmax(v[k].x, v[k].y));
+                in_lo = vmin64(in_lo, vmin64(v[k].x, v[k].y));
+                in_hi = vmax64(in_hi, vmax64(v[k].x, v[k].y));
             }
         }
         double sv[XPL + 4], dv[XPL + 3], lo[XPL], hi[XPL];
@@ -353,8 +360,8 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
                     else (base + (size_t)j * d_sz)[pos0] = clo;
                     (base + (size_t)(m3 + j) * d_sz)[pos0] = chi;
                     if (MM_OUT) {
-                        out_lo = fmin(out_lo, chi); out_hi = fmax(out_hi, chi);
-                        if ((q & 3) != 0 || mm_lll) { out_lo = fmin(out_lo, clo); out_hi = fmax(out_hi, clo); }
+                        out_lo = vmin64(out_lo, chi); out_hi = vmax64(out_hi, chi);
+                        if ((q & 3) != 0 || mm_lll) { out_lo = vmin64(out_lo, clo); out_hi = vmax64(out_hi, clo); }
                     }
                 }
                 p2[q] = D2;
