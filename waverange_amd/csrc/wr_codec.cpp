@@ -180,7 +180,9 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         if (d_plane->shift < 63 && (((uintptr_t)d_fld | (uintptr_t)d_plane->chunk[0]) & 15)) return fail(WR_ERR_ARG, "internal: chunked plane with an unaligned pointer");
         const bool blk = !local && (prev.n > 0 || ilay == 0) && wrk::quantize_plane_blk_ok(d_fld, *d_plane);
         const bool resid_upd = blk ? (s.last && c->keep_residual) : (!s.last || c->keep_residual);
-        uint16_t* const d_hist = blk ? hist_buf(ilay) : nullptr;
+        // (WR_QUANT_HIST=0: the histograms by their own kernel behind the quantizer, for A/B measurements)
+        static const bool hist_fused = !(getenv("WR_QUANT_HIST") && !atoi(getenv("WR_QUANT_HIST")));
+        uint16_t* const d_hist = blk && hist_fused ? hist_buf(ilay) : nullptr;
         launch_note(c, local ? "quant_local" : blk ? (resid_upd ? "quant_blk<1>" : "quant_blk<0>") : resid_upd ? "quant<1>" : "quant<0>", (int)ilay, d_fld, n,
                     c->d_partial, *d_plane);
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
