@@ -538,7 +538,9 @@ api.set_verbosity(0)
 o = Oracle()
 with api.Context(0) as c:
     for shape, tol in (((130, 70, 34), 1e-10), ((128, 64, 80), 1e-16), ((200, 120, 72), 1e-6), ((37, 21, 13), 1e-9), ((61, 1, 1), 1e-7),
-                       ((128, 128, 256), 1e-6), ((64, 64, 144), 1e-4)):
+                       ((128, 128, 256), 1e-6), ((64, 64, 144), 1e-4),
+                       # whole numbers of 60000-symbol coding blocks (an empty final block), and a plane shorter than one 16-byte piece
+                       ((100, 60, 10), 1e-8), ((200, 60, 10), 1e-5), ((3, 2, 2), 1e-9)):
         f = synth.field(*shape, seed=99)
         want = o.encode(f, tol)
         rec_want = o.decode(want, f.shape)
