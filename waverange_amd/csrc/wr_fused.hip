@@ -856,28 +856,34 @@ __global__ __launch_bounds__(256) void k_minmax_final4(const double* __restrict_
 // failure would make every later launch fail with "invalid argument" is checked here, where the cause is still known.
 const char* fused_prepare()
 {
-    static std::once_flag once;
+    // (per device: a process that holds contexts on several GPUs raises the limit on each of them -- the attribute belongs to
+    // the function as loaded on ONE device; the calling thread has its context's device bound)
+    static std::mutex mu;
     static char msg[256];
-    static bool failed = false;
-    std::call_once(once, [] {
-        struct { const void* fn; const char* name; int bytes; } ks[] = {
-            {(const void*)k_fwd_fused<false, false>, "k_fwd_fused<false,false>", (int)LDS_BYTES},
-            {(const void*)k_fwd_fused<true, true>, "k_fwd_fused<true,true>", (int)LDS_BYTES},
-            {(const void*)k_fwd_fused<false, true>, "k_fwd_fused<false,true>", (int)LDS_BYTES},
-            {(const void*)k_inv_fused<false>, "k_inv_fused<false>", (int)LDS_INV},
-            {(const void*)k_inv_fused<true>, "k_inv_fused<true>", (int)LDS_INV}};
-        for (const auto& k : ks) {
-            const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                snprintf(msg, sizeof msg, "fused transform: %s cannot have %d bytes of dynamic LDS (%s); this build is for gfx950 (160 KB of LDS per CU)",
-                         k.name, k.bytes, hipGetErrorString(e));
-                failed = true;
-                return;
-            }
+    static int state[64];  // 0: not tried, 1: ok, 2: failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (state[dev] == 1) return nullptr;
+    if (state[dev] == 2) return msg;
+    struct { const void* fn; const char* name; int bytes; } ks[] = {
+        {(const void*)k_fwd_fused<false, false>, "k_fwd_fused<false,false>", (int)LDS_BYTES},
+        {(const void*)k_fwd_fused<true, true>, "k_fwd_fused<true,true>", (int)LDS_BYTES},
+        {(const void*)k_fwd_fused<false, true>, "k_fwd_fused<false,true>", (int)LDS_BYTES},
+        {(const void*)k_inv_fused<false>, "k_inv_fused<false>", (int)LDS_INV},
+        {(const void*)k_inv_fused<true>, "k_inv_fused<true>", (int)LDS_INV}};
+    for (const auto& k : ks) {
+        const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(msg, sizeof msg, "fused transform: %s cannot have %d bytes of dynamic LDS on device %d (%s); this build is for gfx950 (160 KB of LDS per CU)",
+                     k.name, k.bytes, dev, hipGetErrorString(e));
+            state[dev] = 2;
+            return msg;
         }
-    });
-    return failed ? msg : nullptr;
+    }
+    state[dev] = 1;
+    return nullptr;
 }
 
 // mm_partial != nullptr (needs fused_minmax_records() > 0): min/max of the field and of the coefficient array
