@@ -232,6 +232,43 @@ def take_cpu_share(local_rank, gpus_on_node, gpu_bdfs=()):
         return None
 
 
+class HandoverBuffers:
+    """The coded streams travel from a lane's encoder to its decoder in hand-over buffers, each large enough for any field
+    (setup_wr's bound: virtual memory, only coded bytes are ever touched).  They are not tied to lanes: a buffer that has held
+    a tight-tolerance field keeps that field's 2 GB resident, so a field takes the buffer its own tolerance gave back last (a
+    LIFO per tolerance; a new one if there is none) -- the few-hundred-MB streams of the loose tolerance keep meeting small
+    buffers, and what stays resident is what each tolerance has in flight at a time instead of 2 GB in every buffer there
+    is (165 -> 137 GiB at 32 lanes and 20 steps, profiles/r04/r_*)."""
+
+    def __init__(self, make, limit):
+        import collections
+        import threading
+        self._deque = collections.deque
+        self.make, self.limit = make, limit
+        self.all = []      # every buffer ever made
+        self.idle = {}     # tolerance -> deque of idle buffers that held a field of it last
+        self.lock = threading.Lock()
+
+    def take(self, tol):
+        with self.lock:
+            mine = self.idle.setdefault(tol, self._deque())
+            if mine:
+                return mine.pop()
+            if len(self.all) >= self.limit:
+                raise RuntimeError("bench.py: hand-over buffers leak (%d made; two per lane are in flight at most)" % len(self.all))
+            self.all.append(self.make())
+            return self.all[-1]
+
+    def give(self, tol, buf):
+        with self.lock:
+            self.idle.setdefault(tol, self._deque()).append(buf)
+
+    def reset(self, tol):
+        """every buffer idle again, for fields of `tol` (nothing may be in flight)"""
+        with self.lock:
+            self.idle = {tol: self._deque(self.all)}
+
+
 def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=2.0, host_mem=None):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found})."""
@@ -587,30 +624,9 @@ def main():
             ln["work"], ln["rec"] = ce.alloc(nelem * 8), cd.alloc(nelem * 8)
         lanes.append(ln)
 
-    # The coded streams travel from a lane's encoder to its decoder in hand-over buffers, at most two per lane at a time, each
-    # large enough for any field (setup_wr's bound: virtual memory, only coded bytes are ever touched).  They are not tied to
-    # lanes: a buffer that has held a tight-tolerance field keeps that field's 2 GB resident, so a field takes the buffer its
-    # own tolerance gave back last (a LIFO per tolerance; a new one if there is none) -- the few-hundred-MB streams of the loose
-    # tolerance keep meeting small buffers, and what stays resident is what each tolerance has in flight at a time instead
-    # of 2 GB in every buffer there is.
-    import collections
-    all_bufs = []
-    used_bufs = {}  # tolerance -> deque of idle buffers that held a field of it last
-    buf_lock = threading.Lock()
-
-    def take_buf(tol):
-        with buf_lock:
-            mine = used_bufs.setdefault(tol, collections.deque())
-            if mine:
-                return mine.pop()
-            if len(all_bufs) >= 2 * len(tols) * len(lanes) + 4:
-                raise RuntimeError("bench.py: hand-over buffers leak (two per lane are in flight at most)")
-            all_bufs.append(np.empty(cap, dtype=np.uint8))
-            return all_bufs[-1]
-
-    def give_buf(tol, buf):
-        with buf_lock:
-            used_bufs.setdefault(tol, collections.deque()).append(buf)
+    # hand-over buffers for the coded streams (HandoverBuffers above): at most two per lane in flight at a time
+    bufs = HandoverBuffers(lambda: np.empty(cap, dtype=np.uint8), 2 * len(tols) * len(lanes) + 4)
+    take_buf, give_buf, all_bufs = bufs.take, bufs.give, bufs.all
 
     # host mode: the reconstructions land in one of a few pinned output fields, borrowed for the device half of a
     # decode only (wr_decode_begin / wr_decode_finish_host); the last reconstruction of the last lane is checked
@@ -944,9 +960,7 @@ def main():
             try:
                 for buf in all_bufs:   # the pages of the main run's coded streams go back first: a 1e-16 stream is 6 GB at 1024^3
                     drop_pages(buf, cap)
-                with buf_lock:         # ... and every buffer is in circulation again, for any tolerance (the parity check is done)
-                    used_bufs.clear()
-                    used_bufs[args.secondary_tol] = collections.deque(all_bufs)
+                bufs.reset(args.secondary_tol)  # ... and every buffer is in circulation again (the parity check is done)
                 avail = None
                 with open("/proc/meminfo") as fh:
                     avail = [int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable")][0]

@@ -54,3 +54,29 @@ def test_a_failing_rank_fails_the_launch():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert not any(l.startswith('{"metric"') for l in r.stdout.splitlines())
+
+
+def test_handover_buffers_are_reused_by_tolerance():
+    """bench.py's hand-over buffers: a field takes the buffer its own tolerance gave back last (so that the small streams of
+    a loose tolerance never grow into the 2 GB a tight one leaves resident), a new one if there is none, and a leak is an
+    error instead of unbounded growth."""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    made = []
+    pool = bench.HandoverBuffers(lambda: made.append(object()) or made[-1], limit=5)
+    a, b = pool.take(1e-3), pool.take(1e-7)
+    assert a is not b and len(pool.all) == 2
+    pool.give(1e-7, b)
+    c = pool.take(1e-3)                     # nothing idle for 1e-3: a new buffer, not the 1e-7 one
+    assert c is not b and len(pool.all) == 3
+    assert pool.take(1e-7) is b             # the tight tolerance gets its own buffer back
+    pool.give(1e-3, a); pool.give(1e-3, c)
+    assert pool.take(1e-3) is c and pool.take(1e-3) is a   # LIFO: the one given back last first
+    pool.take(1e-5); pool.take(1e-5)
+    with pytest.raises(RuntimeError):
+        pool.take(1e-5)
+    pool.reset(1e-16)
+    assert {id(pool.take(1e-16)) for _ in range(5)} == {id(x) for x in pool.all}
