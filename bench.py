@@ -74,11 +74,12 @@ def measured_traffic(n):
     return best, src, stale
 
 
-def kernel_sources_sha256():
-    """SHA-256 of the HIP sources whose kernels the PMC traffic figure belongs to."""
+def kernel_sources_sha256(names=("wr_fused.hip",)):
+    """SHA-256 of the HIP sources whose kernels a committed figure belongs to (default: the PMC traffic figure's k_fwd_fused,
+    k_inv_fused)."""
     import hashlib
     out = {}
-    for name in ("wr_fused.hip",):  # the kernels the figure belongs to: k_fwd_fused, k_inv_fused
+    for name in names:
         with open(os.path.join(ROOT, "waverange_amd", "csrc", name), "rb") as fh:
             out[name] = hashlib.sha256(fh.read()).hexdigest()
     return out
@@ -93,19 +94,25 @@ def sha_big(a, chunk=1 << 28):
     return h.hexdigest()
 
 
+def pin_key(n, tol, seed):
+    """key of a pin in tests/golden/large.json (tools/make_golden_large.py): the bench's own field (seed 12345) has the short
+    form, rank r of an N-rank run codes seed 12345 + r"""
+    return "%d^3_tol%g" % (n, tol) + ("" if seed == 12345 else "_seed%d" % seed)
+
+
 def parity_vs_pins(n, seed, coded, decoded):
     """What the TIMED run produced against the reference's own outputs (tests/golden/large.json, written by
     tools/make_golden_large.py from the compiled reference in the build container): the coded bytes of the last field
     of every tolerance (header scalars as bit patterns, plane lengths, SHA-256 of data_enc) and the last reconstruction.
-    Runs after the timed region.  None where no pin exists for (size, tolerance, seed)."""
+    Runs after the timed region, on every rank for its own field.  None where no pin exists for (size, tolerance, seed)."""
     try:
         with open(os.path.join(ROOT, "tests", "golden", "large.json")) as fh:
             pins = json.load(fh)
     except OSError:
         return {"fixture": None}
-    out = {"fixture": "tests/golden/large.json", "coded_sha_ok": None, "decoded_sha_ok": None, "checked": []}
+    out = {"fixture": "tests/golden/large.json", "seed": seed, "coded_sha_ok": None, "decoded_sha_ok": None, "checked": []}
     for tol, enc in coded.items():
-        rec = pins.get("%d^3_tol%g" % (n, tol))
+        rec = pins.get(pin_key(n, tol, seed))
         if not rec or rec["seed"] != seed:
             continue
         ok = (enc["nlay"] == rec["nlay"] and [int(v) for v in enc["len_enc_vec"]] == rec["len_enc_vec"] and int(enc["ntot_enc"]) == rec["ntot_enc"]
@@ -116,10 +123,51 @@ def parity_vs_pins(n, seed, coded, decoded):
         out["checked"].append("coded %d^3 tol %g" % (n, tol))
     if decoded is not None:
         tol, arr = decoded
-        rec = pins.get("%d^3_tol%g" % (n, tol))
+        rec = pins.get(pin_key(n, tol, seed))
         if rec and rec["seed"] == seed:
             out["decoded_sha_ok"] = sha_big(arr) == rec["decoded_sha256"]
             out["checked"].append("reconstruction %d^3 tol %g" % (n, tol))
+    return out
+
+
+def committed_kernel_stats():
+    """The rocprofv3 --kernel-trace --stats summary committed under profiles/ (latest round's final_kernel_stats.csv, copied
+    there by tools/kernel_stats_meta.py together with the hashes of the kernel sources it was taken on): per-transform
+    durations of the same kernels this run times with HIP events, and whether the sources have changed since (stale)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final_kernel_stats.csv")))
+    if not files:
+        return None
+    f = files[-1]
+    out = {"source": os.path.relpath(f, ROOT), "stale": None}
+    try:
+        with open(f[:-4] + ".meta.json") as fh:
+            meta = json.load(fh)
+        out["stale"] = meta.get("kernel_sources_sha256") != kernel_sources_sha256(("wr_fused.hip", "wr_kernels.hip"))
+        out["taken_on"] = meta.get("head")
+        out["clock_warmup_ms"] = meta.get("clock_warmup_ms")
+    except (OSError, ValueError):
+        pass
+    try:
+        avg, calls = {}, {}
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                avg[r["Name"]], calls[r["Name"]] = float(r["AverageNs"]) * 1e-6, int(r["Calls"])
+
+        def pick(sub):
+            return [(k, avg[k], calls[k]) for k in avg if sub in k]
+        # an encode's forward transform is one <true, true> launch (level 0, min/max riding along) and three <false, true>
+        # ones; an inverse is four k_inv_fused launches (all levels in one row of the stats)
+        f0, f1, inv = pick("k_fwd_fused<true, true>"), pick("k_fwd_fused<false, true>"), pick("k_inv_fused")
+        if f0 and f1:
+            out["fwd_ms"] = round(f0[0][1] + 3.0 * f1[0][1], 3)
+        if inv:
+            out["inv_ms"] = round(4.0 * inv[0][1], 3)
+        burn = pick("k_burn")
+        out["k_burn_calls"] = burn[0][2] if burn else 0
+    except (OSError, ValueError, KeyError):
+        pass
     return out
 
 
@@ -269,24 +317,38 @@ class HandoverBuffers:
             self.idle = {tol: self._deque(self.all)}
 
 
-def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4, fields_per_cpu=2.0, host_mem=None):
+class SizingRefused(SystemExit):
+    """this rank cannot run the workload in the host memory it has: the message carries the arithmetic"""
+
+
+def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4,
+             fields_per_cpu=2.0, host_mem=None, cpus=None, local_world=None):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
-    memory and the free HBM.  Returns (jobs, {what was found})."""
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    cpus = float(len(os.sched_getaffinity(0)))
+    memory and the free HBM.  Returns (jobs, {what was found}).  Host memory decides in three steps (a rank never allocates
+    what its share cannot hold: an 8-GPU node with little memory per GPU must not turn its first run into an OOM kill):
+      ample       the lanes the CPUs want fit with coded streams left resident (0.6 field sizes per lane) next to the fixed
+                  buffers (the input field and `out_pool` output fields);
+      tight       fewer lanes, consumed coded streams hand their pages back (0.25 field sizes per lane); if not even one lane
+                  per tolerance fits, the output pool shrinks to ONE field (decodes then take turns for it);
+      impossible  2 + 0.25 x ntols field sizes do not fit 80 % of the share: SizingRefused with the arithmetic (the caller
+                  may retry at a smaller --size; main() does so once, loudly, for --size 1024 -> 512)."""
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     quota = None  # CPU quota of the whole job (all ranks), if any
-    q = _cgroup_number("/sys/fs/cgroup/cpu.max")  # cgroup v2
-    if q and q[0] != "max":
-        quota = float(q[0]) / float(q[1])
-    q1, p1 = _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_period_us")  # v1
-    if q1 and p1 and float(q1[0]) > 0:
-        quota = min(quota, float(q1[0]) / float(p1[0])) if quota else float(q1[0]) / float(p1[0])
-    if pinned_share:
-        # the affinity has been cut down to this rank's GPU's share of the node; a quota is split the same way,
-        # whether 1 or 8 ranks run
-        cpus = min(float(pinned_share), quota / gpus_on_node) if quota else float(pinned_share)
-    else:
-        cpus = (min(cpus, quota) if quota else cpus) / local_world
+    if cpus is None:
+        cpus = float(len(os.sched_getaffinity(0)))
+        q = _cgroup_number("/sys/fs/cgroup/cpu.max")  # cgroup v2
+        if q and q[0] != "max":
+            quota = float(q[0]) / float(q[1])
+        q1, p1 = _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), _cgroup_number("/sys/fs/cgroup/cpu/cpu.cfs_period_us")  # v1
+        if q1 and p1 and float(q1[0]) > 0:
+            quota = min(quota, float(q1[0]) / float(p1[0])) if quota else float(q1[0]) / float(p1[0])
+        if pinned_share:
+            # the affinity has been cut down to this rank's GPU's share of the node; a quota is split the same way,
+            # whether 1 or 8 ranks run
+            cpus = min(float(pinned_share), quota / gpus_on_node) if quota else float(pinned_share)
+        else:
+            cpus = (min(cpus, quota) if quota else cpus) / local_world
     # host memory like the CPUs: a rank sizes itself to its GPU's share of the node whether 1 or 8 ranks run, so that
     # the per-GPU work does not change with N (weak scaling measures GPUs, not how much idle memory one rank can borrow)
     mem_share = max(local_world, gpus_on_node if pinned_share else 1)
@@ -306,30 +368,69 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # with the coder pool the lanes are not threads: a field in flight spends part of its time in copies and kernels and
     # waiting for its slowest plane, so 1.5 fields in flight per CPU keep the pool's workers busy (16 lanes on 16 CPUs:
     # 12.2 CPUs busy on average)
-    by_cpu = int(fields_per_cpu * cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols))
+    by_cpu = max(1, int(fields_per_cpu * cpus // ntols) if pooled else int(1.25 * cpus // (2 * ntols)))
     # host memory per field in flight: the coded streams only (two hand-over buffers that have each held a 1e-7 field's
     # 2 GB at some point, and the coder's output while it is being produced: ~0.6 field sizes at the bench's tolerances,
     # 0.75 budgeted) and the pinned rings (0.25 GiB) -- the quantized planes stay in HBM; the input
     # field and the pool of output fields (two-phase decode) are a fixed 1 + out_pool field sizes in host-to-host mode.
     # HBM per field in flight: the planes of its encoder and decoder contexts (up to 4 + 4 at the bench's tolerances =
     # one field size) next to three work-space slots of 2.2 field sizes; resident mode: two field buffers per lane more
-    per_lane = 0.6 * field_bytes
-    fixed = (1 + out_pool) * field_bytes if host_mode else 0
-    by_mem = int((0.8 * mem / mem_share - fixed) // (per_lane * ntols)) if mem else want
-    # if host memory is what holds the lanes back, consumed coded streams hand their pages back to the system (drop_pages):
-    # ~0.25 field sizes per lane instead of 0.6, at ~3 % of the rate (the pages are faulted in and zeroed again for every field)
-    trim = False
-    if mem and by_mem < min(want, int(fields_per_cpu * cpus // ntols) if pooled else want):
-        trim = True
-        by_mem = int((0.8 * mem / mem_share - fixed) // (0.25 * field_bytes * ntols))
+    regime, trim, by_mem, budget = "ample", False, want, None
+    if mem:
+        budget = 0.8 * mem / mem_share
+        fixed = (1 + out_pool) * field_bytes if host_mode else 0
+        by_mem = int((budget - fixed) // (0.6 * field_bytes * ntols))
+        if by_mem < min(want, by_cpu):
+            # consumed coded streams hand their pages back to the system (drop_pages): ~0.25 field sizes per lane instead of
+            # 0.6, at ~3 % of the rate (the pages are faulted in and zeroed again for every field)
+            regime, trim = "tight", True
+            by_mem = int((budget - fixed) // (0.25 * field_bytes * ntols))
+            if by_mem < 1 and host_mode and out_pool > 1:
+                out_pool = 1
+                fixed = 2 * field_bytes
+                by_mem = int((budget - fixed) // (0.25 * field_bytes * ntols))
+            if by_mem < 1:
+                need = fixed + 0.25 * field_bytes * ntols
+                raise SizingRefused(
+                    "bench.py: this rank's share of the host memory cannot hold the workload: %.1f GiB available / %d ranks on the node x 0.8 = %.1f GiB, "
+                    "but the smallest configuration -- input field + one output field (2 x %.1f GiB) + one lane per tolerance (%d x 0.25 x %.1f GiB of "
+                    "coded streams) -- needs %.1f GiB.  Use a smaller --size, fewer --tols, or a node with more memory per GPU."
+                    % (mem / 2 ** 30, mem_share, budget / 2 ** 30, field_bytes / 2 ** 30, ntols, field_bytes / 2 ** 30, need / 2 ** 30))
     # (planes_per_field: 1 byte per element and plane, encoder and decoder context of a lane each hold a field's planes)
     # an encoder's planes drain as its coder advances (half of them are gone on average), a decoder's stay until its field is
     # done: 0.75 of the two contexts' worst case; a call that finds no room for a plane waits for chunks to come back
     by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((0.75 * planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
-    jobs = max(1, min(want, by_cpu, by_mem, by_hbm))
+    if by_hbm < 1:
+        raise SizingRefused("bench.py: %.1f GiB of free HBM cannot hold %d work-space slots (2.2 x %.1f GiB each) and one lane per tolerance"
+                            % (hbm_free / 2 ** 30, nslots, field_bytes / 2 ** 30))
+    jobs = min(want, by_cpu, by_mem, by_hbm)
     return jobs, {"jobs_requested": want, "cpus_per_rank": round(cpus, 1), "host_mem_per_rank_gib": round(mem / mem_share / 2 ** 30, 1) if mem else None,
                   "hbm_free_gib": round(hbm_free / 2 ** 30, 1), "jobs_by_cpu": by_cpu, "jobs_by_host_mem": by_mem, "jobs_by_hbm": by_hbm,
+                  "host_memory_regime": regime, "out_buffers": out_pool if host_mode else 0,
                   "host_pages_of_consumed_streams_dropped": trim}
+
+
+def fit_jobs_or_smaller(size, *args, **kw):
+    """fit_jobs at `size`; if the rank's memory refuses a 1024^3 workload, once more at 512^3 (BASELINE configs[3]'s field
+    size) -- returns (size actually sized for, jobs, sizing); the sizing says so (`fell_back_from_size`).  Anything that does
+    not fit 512^3 either is refused."""
+    def at(n):
+        a = list(args)
+        a[2] = n ** 3 * 8  # field_bytes
+        return fit_jobs(*a, **kw)
+    try:
+        jobs, info = at(size)
+        return size, jobs, info
+    except SizingRefused as first:
+        if size <= 512:
+            raise
+        try:
+            jobs, info = at(512)
+        except SizingRefused:
+            raise first
+        info["fell_back_from_size"] = size
+        info["refusal_at_that_size"] = str(first)
+        return 512, jobs, info
 
 
 def cpu_model():
@@ -470,6 +571,14 @@ def main():
     tols = [float(t) for t in args.tols.split(",")]
     n = args.size
     host_mode = not args.resident
+    # Before anything touches the GPU or loads a library: (1) this pool's host driver only supports dmabuf IPC -- without
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's set-up between two ranks fails with `hipIpcGetMemHandle: invalid argument`; the
+    # variable is read when the ROCm runtime initialises, so it must be in the environment of EVERY rank, whoever started it
+    # (launch_ranks sets it for its children, an external launcher such as torch.distributed.run does not);  (2) the library's
+    # launch ring (a SIGABRT handler that names the last plane-kernel launches, WR_FAULT_LOG) costs nothing and is the only
+    # witness if a GPU fault ends a rank inside the runtime on a node nobody can log into.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("WR_FAULT_LOG", "1")
 
     # N ranks: under a launcher (the driver's torch.distributed.run) WORLD_SIZE is set and this process is one of
     # them; started plainly with --gpus N > 1 this process is their parent (nothing below may run in it)
@@ -493,16 +602,21 @@ def main():
             mine = cpu_share_of(local_rank, local_world, read_cpu_topology(()))
             if mine:
                 os.sched_setaffinity(0, mine)
-            jobs, sizing = fit_jobs(args.jobs, len(tols), n ** 3 * 8, int(0.97 * 288e9), len(mine) if mine else None, host_mode,
-                                    pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=local_world, nslots=args.slots or 3,
-                                    planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
-            sizing.update(lanes=jobs * len(tols), cpu_affinity_share=len(mine) if mine else None,
+            hm = int(os.environ["WR_BENCH_TEST_HOST_MEM_GIB"]) << 30 if os.environ.get("WR_BENCH_TEST_HOST_MEM_GIB") else None  # (tests: a node's memory)
+            size_for, jobs, sizing = fit_jobs_or_smaller(n, args.jobs, len(tols), n ** 3 * 8, int(0.97 * 288e9), len(mine) if mine else None, host_mode,
+                                                         pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=local_world, nslots=args.slots or 3,
+                                                         planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu, host_mem=hm)
+            sizing.update(size=size_for, lanes=jobs * len(tols), cpu_affinity_share=len(mine) if mine else None,
                           cpus=",".join("%d" % c for c in sorted(os.sched_getaffinity(0))) if len(os.sched_getaffinity(0)) <= 64 else "%d CPUs" % len(os.sched_getaffinity(0)))
+        except SizingRefused as e:
+            print(json.dumps({"dry_launch": True, "rank": rank, "world_size": world, "sizing": {"refused": str(e)}}), flush=True)
+            raise
         except (OSError, ValueError) as e:
             sizing = {"error": str(e)}
         print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
                           "launched_by": "bench.py" if os.environ.get("WR_BENCH_CHILD") else "external launcher" if world > 1 else "none",
+                          "environment": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "WR_FAULT_LOG")},
                           "sizing": sizing}), flush=True)
         return
 
@@ -564,9 +678,16 @@ def main():
         # ranks' CPU shares, lanes and memory shares are the ones of the real run
         gpus_on_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         share = take_cpu_share(local_rank, gpus_on_node, ())
-    jobs, limits = fit_jobs(args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
-                            pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=gpus_on_node, nslots=args.slots or 3,
-                            planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
+    # (SizingRefused -- a rank whose share of the host memory cannot hold even the smallest configuration -- ends the rank with a
+    # non-zero status and the arithmetic on stderr before it has allocated anything; under a launcher the other ranks follow)
+    n, jobs, limits = fit_jobs_or_smaller(n, args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
+                                          pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=gpus_on_node, nslots=args.slots or 3,
+                                          planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
+    if limits.get("fell_back_from_size") and rank == 0:
+        print("bench.py: --size %d does not fit this rank's host memory, running --size %d instead: %s"
+              % (limits["fell_back_from_size"], n, limits["refusal_at_that_size"]), file=sys.stderr)
+    if host_mode:
+        args.out_buffers = limits["out_buffers"]
     limits["cpu_affinity_share"] = share
 
     def cpu_ranges(cpus):
@@ -646,7 +767,7 @@ def main():
             amax = max(amax, float(np.abs(a).max()))
         return diff / amax
 
-    last_coded, last_decoded = {}, []
+    main_capture = {"coded": {}, "decoded": []}
     import ctypes
     libc = ctypes.CDLL(None, use_errno=True)
     libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -667,10 +788,12 @@ def main():
     lock = threading.Lock()
     errors = []
 
-    def run_steps(nsteps, record, tols=tols, lanes=lanes, batch=batch, trim_host=trim_host):
+    def run_steps(nsteps, record, tols=tols, lanes=lanes, batch=batch, trim_host=trim_host, capture=None):
         """nsteps steps = nsteps x batch fields (field i at tolerance tols[i % len(tols)]), pulled from one queue by the
         lanes; returns when all of them have been encoded AND decoded.  (The secondary pass runs other tolerances on
-        fewer lanes: the keyword arguments.)"""
+        fewer lanes: the keyword arguments.)  capture: {"coded": {}, "decoded": []} -- the coded bytes of the last field of every
+        tolerance and the last reconstruction are held back there (their buffers stay out of circulation) for the parity
+        check after the run."""
         total = nsteps * batch
         nxt = [0]
 
@@ -706,8 +829,8 @@ def main():
                             ln["enc"].copy(ln["work"], orig, nelem * 8)
                             enc, te = ln["enc"].encode(ln["work"], shape, tol, out=buf)
                         box[k & 1] = (enc, te, tol, i, buf)
-                        if record and i >= total - len(tols):
-                            last_coded[tol] = enc   # its buffer is not written again: no field follows on any lane
+                        if capture is not None and i >= total - len(tols):
+                            capture["coded"][tol] = (enc, buf)   # its buffer is not written again: no field follows on any lane
                         coded[k & 1].release()
                         k += 1
                 except Exception as exc:
@@ -726,7 +849,7 @@ def main():
                             return
                         enc, te, tol, i, buf = item
                         # (the last field of every tolerance keeps its buffer out of circulation: parity is taken from it later)
-                        held_back = record and i >= total - len(tols)
+                        held_back = capture is not None and i >= total - len(tols)
                         if host_mode:
                             ln["dec"].decode_begin(shape, enc)       # host range decoding: seconds, no field buffer
                             if trim_host and not held_back:
@@ -738,8 +861,8 @@ def main():
                             keep = False
                             try:
                                 td = ln["dec"].decode_finish_host(out)  # kernels, download: ~0.25 s
-                                if record and i == total - 1:
-                                    last_decoded.append((tol, out))  # held back: accuracy and parity are taken after the timed region
+                                if capture is not None and i == total - 1:
+                                    capture["decoded"].append((tol, out))  # held back: accuracy and parity are taken after the timed region
                                     keep = True
                             finally:
                                 if not keep:
@@ -792,6 +915,7 @@ def main():
     thr0 = throttled_s()
     cpu0 = sum(os.times()[:2])
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
+    burn0 = api.stat(api.STAT_CLOCK_WARMUP_MS)
     queue0, pwait0 = api.stat(api.STAT_POOL_QUEUE_MS), api.stat(api.STAT_PLANE_WAIT_MS)
     loops0 = api.pool_loop_stats()
     sampler = stop_sampling = None
@@ -814,7 +938,7 @@ def main():
     t0 = time.perf_counter()
     if sampler:
         sampler.start()
-    run_steps(args.steps, True)
+    run_steps(args.steps, True, capture=main_capture)
     barrier()
     dt = time.perf_counter() - t0
     if sampler:
@@ -825,6 +949,7 @@ def main():
     nfields = max(1, args.steps * batch)
     queue_wait = (api.stat(api.STAT_POOL_QUEUE_MS) - queue0) * 1e-3 / nfields   # per field: its planes' waits for a pool worker, summed
     plane_wait = (api.stat(api.STAT_PLANE_WAIT_MS) - pwait0) * 1e-3 / nfields   # per field: waits for device memory for its planes
+    burn_ms = (api.stat(api.STAT_CLOCK_WARMUP_MS) - burn0) / float(nfields)     # per field: clock warm-up load in front of its two kernel stages (0 unless WR_CLOCK_WARMUP_MS)
     loops1 = api.pool_loop_stats()
     pool_loops = {}
     for kind in loops1:  # in-pipeline rate of every coder loop: symbols per worker-second, workers busy in it on average
@@ -840,14 +965,41 @@ def main():
 
     # accuracy of the last reconstruction (tols[-1]) against the original, and the bytes of the timed run against the
     # reference's pins -- outside the timed region
-    parity = None
-    if host_mode and last_decoded:
-        accuracy["linf_rel"] = linf_vs_input(last_decoded[0][1])
-    if rank == 0 and host_mode:
-        parity = parity_vs_pins(n, 12345 + rank, last_coded, last_decoded[0] if last_decoded else None)
-    for _, buf in last_decoded:
-        out_pool.put(buf)
+    def check_capture(cap):
+        """accuracy of the held-back reconstruction and parity of the held-back bytes against this rank's pins; everything that
+        was held back goes into circulation again"""
+        res = {"linf_rel": None, "parity": None}
+        if host_mode and cap["decoded"]:
+            res["linf_rel"] = linf_vs_input(cap["decoded"][0][1])
+        if host_mode:
+            res["parity"] = parity_vs_pins(n, 12345 + rank, {t: e for t, (e, _) in cap["coded"].items()}, cap["decoded"][0] if cap["decoded"] else None)
+        for _, out_field in cap["decoded"]:
+            out_pool.put(out_field)
+        for t, (_, buf) in cap["coded"].items():
+            give_buf(t, buf)
+        cap["coded"].clear()
+        cap["decoded"][:] = []
+        return res
+
+    # EVERY rank checks what it coded in the timed region against the reference's pins for its own field (seed 12345 + rank)
+    main_check = check_capture(main_capture)
+    parity = main_check["parity"]
+    if main_check["linf_rel"] is not None:
+        accuracy["linf_rel"] = main_check["linf_rel"]
     linf_rel = accuracy.get("linf_rel")
+    if dist is not None and world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, {"rank": rank, "parity": parity, "linf_rel": linf_rel})
+        if rank == 0 and parity is not None:
+            def ok(p):  # everything that could be checked was right, and something was checked
+                return bool(p and p["checked"] and p["coded_sha_ok"] is not False and p["decoded_sha_ok"] is not False
+                            and (p["coded_sha_ok"] or p["decoded_sha_ok"]))
+            parity = dict(parity, ranks_ok=sum(1 for e in every if ok(e["parity"])),
+                          ranks_without_pins=[e["rank"] for e in every if not (e["parity"] and e["parity"]["checked"])],
+                          ranks_failed=[e["rank"] for e in every if e["parity"] and (e["parity"]["coded_sha_ok"] is False or e["parity"]["decoded_sha_ok"] is False)],
+                          linf_rel_max=max([e["linf_rel"] for e in every if e["linf_rel"] is not None] or [None]))
+    elif parity is not None:
+        parity = dict(parity, ranks_ok=1 if (parity["checked"] and parity["coded_sha_ok"] is not False and parity["decoded_sha_ok"] is not False) else 0)
 
     mean = lambda v: float(sum(v) / max(1, len(v)))  # noqa: E731
     if rank == 0:
@@ -890,10 +1042,16 @@ def main():
                        "pipeline": "a step is a batch of %d fields (%d per tolerance); the %d lanes (encoder + decoder context each) pull fields from the run's queue, "
                                    "so steps overlap: a lane encodes its next field while it decodes the previous one" % (batch, batch // len(tols), len(lanes)),
                        "planes": {("%g" % t): stats[t] for t in tols}},
+            # the figure of the library AS SHIPPED: inside the pipeline, every kernel stage starting on a GPU that has been idle
+            # (no clock warm-up: WR_CLOCK_WARMUP_MS is a measurement hook that is off by default; if this run set it, `condition`
+            # says so).  Beside it: roofline_warm, the same kernels back to back with the shader clock up.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": "3-D CDF-9/7 transform, 4 levels (mean of forward and inverse), all launches",
-                         "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3)},
+                         "algorithmic_bytes": alg_bytes, "fwd_ms": round(fwd_ms, 3), "inv_ms": round(inv_ms, 3),
+                         "condition": ("in the pipeline, shipped default: no clock warm-up, a kernel stage starts on an idle GPU" if burn_ms == 0 else
+                                       "in the pipeline behind WR_CLOCK_WARMUP_MS=%s of load (NOT the shipped default)" % os.environ.get("WR_CLOCK_WARMUP_MS")),
+                         "rocprof_kernel_stats": committed_kernel_stats()},
             # the other kernel groups: algorithmic bytes per element L + 8 (dequantise-accumulate), 8 per min/max
             # pass (two passes per encode); times from HIP events in the run.  Quantizer: SURVEY.md 8d counts the reference's
             # formulation, 17 L - 8 (the residual array read and rewritten by every plane but the last); the kernels here cut
@@ -919,6 +1077,7 @@ def main():
                                 "decode_planes_h2d_ms": round(mean(acc["dec_h2d_ms"]), 2), "decode_field_d2h_ms": round(mean(acc["dec_d2h_ms"]), 2),
                                 "field_h2d_GBps": round(nbytes_field / 1e6 / max(1e-9, mean(acc["enc_h2d_ms"])), 1) if host_mode else None,
                                 "field_d2h_GBps": round(nbytes_field / 1e6 / max(1e-9, mean(acc["dec_d2h_ms"])), 1) if host_mode else None},
+                       "burn_ms_per_field": round(burn_ms, 2),
                        "device_only_MBps": round(2 * field_mb / max(1e-9, mean(acc["enc_gpu_s"]) + mean(acc["dec_gpu_s"])), 1)},
             "accuracy": {"tol": tols[-1], "linf_rel": linf_rel},
             "parity": parity,
@@ -935,7 +1094,8 @@ def main():
             wbuf.free()
             wa = alg_bytes / (0.5 * (wf + wi) * 1e-3) / 1e9
             out["roofline_warm"] = {"achieved": round(wa, 1), "frac": round(wa / HBM_PEAK_GBS, 4), "fwd_ms": round(wf, 3), "inv_ms": round(wi, 3),
-                                    "note": "plain forward kernels (no min/max riding along), 8 transforms back to back after 12 to warm up"}
+                                    "note": "plain forward kernels (no min/max riding along), 8 transforms back to back after 12 to warm up: the shader clock is up "
+                                            "(what WR_CLOCK_WARMUP_MS buys inside the pipeline; it does not move `value`)"}
         except Exception as exc:  # noqa: BLE001
             out["roofline_warm"] = {"error": str(exc)}
         other, other_src = committed_extra("bench%d_resident.json" % n if host_mode else "bench%d_host.json" % n)
@@ -972,12 +1132,17 @@ def main():
                 sb = nl  # one field per lane and step
                 t2 = time.perf_counter()
                 stats[args.secondary_tol] = {}
-                run_steps(args.secondary_steps, False, tols=[args.secondary_tol], lanes=lanes[:nl], batch=sb, trim_host=True)
+                sec_capture = {"coded": {}, "decoded": []}
+                run_steps(args.secondary_steps, False, tols=[args.secondary_tol], lanes=lanes[:nl], batch=sb, trim_host=True, capture=sec_capture)
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t2
+                sec_planes = {"nlay": sec_capture["coded"][args.secondary_tol][0]["nlay"], "ntot_enc": int(sec_capture["coded"][args.secondary_tol][0]["ntot_enc"])} \
+                    if args.secondary_tol in sec_capture["coded"] else None
+                sec_check = check_capture(sec_capture)  # the last field's bytes and reconstruction against the reference's pin at this tolerance
                 out["secondary"] = {"tol_%g" % args.secondary_tol: {
                     "value": round(args.secondary_steps * sb * field_mb / dt2, 2), "unit": "MB/s", "lanes": nl, "steps": args.secondary_steps,
                     "fields": args.secondary_steps * sb, "seconds": round(dt2, 1),
+                    "planes": sec_planes, "accuracy": {"tol": args.secondary_tol, "linf_rel": sec_check["linf_rel"]}, "parity": sec_check["parity"],
                     "note": "BASELINE configs[4]'s tolerance (8 planes per field, six of them noise) through the same pipeline after the timed region; "
                             "a bounded sample -- %d fields on %d lanes, fill and drain included -- not the steady-state rate (`bench.py --tols %g`)"
                             % (args.secondary_steps * sb, nl, args.secondary_tol)}}
@@ -997,9 +1162,17 @@ def main():
                 ln["enc"].copy(ln["work"], orig, nelem * 8)
                 enc1, te1 = ln["enc"].encode(ln["work"], shape, tols[-1], out=take_buf(tols[-1]))
                 td1 = ln["dec"].decode(ln["rec"], shape, enc1)
+            L1 = enc1["nlay"]
             out["single_field"] = {"tol": tols[-1], "coder_threads": "one per plane", "encode_s": round(te1["total"], 3),
                                    "decode_s": round(td1["total"], 3),
-                                   "MBps": round(field_mb / (te1["total"] + td1["total"]), 1)}
+                                   "MBps": round(field_mb / (te1["total"] + td1["total"]), 1),
+                                   # one encoding_wrap / decoding_wrap call is as long as its slowest plane stream: a serial recurrence per
+                                   # plane (rangecod.c:217-229, 309-351) that no number of cores shortens; throughput comes from concurrent calls
+                                   "plane_streams": [{"plane": l, "bits_per_symbol": round(8.0 * enc1["len_enc_vec"][l] / nelem, 3),
+                                                      "encode_Msym_per_s": round(nelem / max(1e-9, te1["plane_coder_s"][l]) / 1e6, 1),
+                                                      "decode_Msym_per_s": round(nelem / max(1e-9, td1["plane_coder_s"][l]) / 1e6, 1)} for l in range(L1)],
+                                   "bound_by": "the slowest plane stream: encode %.2f s, decode %.2f s of the call's %.2f / %.2f s"
+                                               % (te1["rangecoder"], td1["rangecoder"], te1["total"], td1["total"])}
             api.set_threads(args.threads, args.enc_threads)
             ncores = max(1, int(limits["cpus_per_rank"]))
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, tols, ncores)

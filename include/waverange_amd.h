@@ -142,6 +142,8 @@ typedef struct wr_timings {
     float h2d_ms;       /* host entry points: upload of the field (encode) / the planes (decode) */
     float d2h_ms;       /* host entry points: sum of the plane downloads (encode) / download of the field
                            (decode); engine timestamps for DMA copies */
+    double plane_coder_s[WR_NLAYMAX]; /* host range coder, per plane: from the moment a coder took the plane's stream to its end (a
+                           call is as long as its SLOWEST plane stream: `rangecoder` is the maximum of these) */
 } wr_timings;
 
 const char *wr_last_error(void);
@@ -177,18 +179,20 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_DEVICE_PLANE_BYTES 2 /* device memory of quantized planes allocated right now (in use + idle), all devices */
 #define WR_STAT_POOL_IDLE_MS 3  /* milliseconds the coder pool's workers have waited for a job, summed over the workers */
 #define WR_STAT_POOL_STREAMS_MOVED 4  /* plane streams that changed pool workers between two blocks: an idle worker takes over half
-                                        of the streams of the fullest running session (WR_POOL_STEAL=0 turns that off) */
+                                        of the streams of the fullest running session */
 #define WR_STAT_POOL_QUEUE_MS 5  /* milliseconds plane jobs have waited in the coder pool's queues before a worker took them, summed over jobs */
 #define WR_STAT_PLANE_WAIT_MS 6  /* milliseconds calls have waited for device memory for their quantized planes (a decoder also: for its turn
                                     to gather them), summed over calls */
 #define WR_STAT_HANDOVER_ERRORS 7  /* window requests of a host coder that were refused: the plane stream they named had moved on to another
                                       call, they came out of order, or two coders were inside one stream (always 0 in a correct run; the
                                       call concerned fails) */
+#define WR_STAT_CLOCK_WARMUP_MS 8  /* milliseconds of clock warm-up load put in front of kernel stages (WR_CLOCK_WARMUP_MS, a measurement
+                                      hook that is off by default: always 0 then) */
 unsigned long wr_stat(int what);
-/* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder,
- * 16-lane decoder for planes of any statistics} -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block
- * steps of that loop and stream-blocks (60000 symbols) advanced: symbols per worker-second in the pipeline */
-#define WR_POOL_LOOP_KINDS 5
+/* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder}
+ * -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block steps of that loop and stream-blocks (60000
+ * symbols) advanced: symbols per worker-second in the pipeline */
+#define WR_POOL_LOOP_KINDS 4
 void wr_pool_loop_stats(double *seconds, double *blocks);
 
 /* One context per concurrent caller: (device, kernel stream, coded-stream buffers, and per plane a ring
@@ -328,15 +332,11 @@ int wr_range_encode_vec(int count, const unsigned char *const *sym, const size_t
                         unsigned char *const *out, size_t *lens);
 int wr_range_decode_vec(int count, const unsigned char *const *in, const size_t *len,
                         unsigned char *const *sym, const size_t *n, size_t *produced);
-/* the decoder's 16-lane loop for planes of ANY statistics (low / help by vector division, table look-ups per lane: what
- * noise planes need; the pool routes the decoder planes above 2 bits per symbol there) */
-int wr_range_decode_vec_any(int count, const unsigned char *const *in, const size_t *len,
-                            unsigned char *const *sym, const size_t *n, size_t *produced);
 
 /* Test hooks for the windowed symbol path: planes that live in device memory reach the host coder through a small
  * pinned ring, window by window (wr_encode_host / wr_decode_*); here the windows are `chunk` symbols (a multiple of
  * 60000) of plain host buffers.  mode 0: interleaved loops on the calling thread, 1: the coder pool, 2: the 16-lane
- * loops, 3: (decode) the 16-lane loop for planes of any statistics.  Same bytes / symbols as the whole-plane functions above. */
+ * loops.  Same bytes / symbols as the whole-plane functions above. */
 int wr_range_encode_windowed(int mode, int count, const unsigned char *const *sym, size_t n, size_t chunk,
                              unsigned char *const *out, size_t *lens);
 int wr_range_decode_windowed(int mode, int count, const unsigned char *const *in, const size_t *len,

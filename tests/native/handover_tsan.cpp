@@ -1,5 +1,5 @@
 // ThreadSanitizer / AddressSanitizer harness for the plane hand-over (CPU build only; sanitizers are not available on the
-// GPU pool): the product's coder pool (wr_rangecoder.cpp, streams changing workers forced with WR_POOL_STEAL_IDLE=1) codes
+// GPU pool): the product's coder pool (wr_rangecoder.cpp, streams changing workers forced: pool_test_steal_idle_min(1)) codes
 // planes that it sees only through window requests, against a mock of wr_pipeline.cpp's PlaneStream that keeps the
 // product's rules (wr_handover.h: generations and tickets, one request at a time, windows in order, nothing after the end)
 // and the product's storage behaviour: a plane lives in chunks that are FREED as an encoder's windows pass them (so ASan
@@ -58,12 +58,10 @@ struct MockPlane {
         ho.retire();
         io.window = nullptr; io.user = nullptr;
     }
-    static uint8_t* refuse(size_t* count)
+    static uint8_t* refuse(size_t*)
     {
         g_refused++;
-        static uint8_t sink[kWindow];
-        if (*count > kWindow) *count = kWindow;
-        return *count ? sink : nullptr;
+        return nullptr;  // a refused request hands nothing out (wrrc::PlaneWindow): the coder gives the stream up
     }
     static uint8_t* window_encode(void* user, size_t first, size_t* count)
     {
@@ -121,7 +119,7 @@ static void fill_plane(std::vector<uint8_t>& p, int kind, unsigned long long& s)
 
 int main()
 {
-    setenv("WR_POOL_STEAL_IDLE", "1", 1);  // any idle worker takes over half of the fullest session at its next block boundary
+    wrrc::pool_test_steal_idle_min(1);  // any idle worker takes over half of the fullest session at its next block boundary
     constexpr int kCallers = 4, kPlanes = 5, kRounds = 3;
     const size_t sizes[kPlanes] = {(size_t)60000 * 7 + 123, (size_t)60000 * 6, (size_t)60000 * 9 + 1, (size_t)60000 * 4 + 59999, (size_t)60000 * 8};
     wrrc::pool_configure(6, 4);
@@ -226,6 +224,46 @@ int main()
         c = 0; (void)p.io.window(p.io.user, MockPlane::kWindow, &c);
         c = n - MockPlane::kWindow; (void)p.io.window(p.io.user, MockPlane::kWindow, &c);
         if (g_refused.load() != 6) { printf("decoder window after the end served\n"); return 1; }
+    }
+    // ---- a real coder on a refused window: the stream ends at once with (size_t)-1, nothing is written or read beyond what
+    // was served (ASan: the output buffers are exact-size; the advisor's case: an encoder that "ran on" on a zeroed scratch
+    // window against the GPU's histograms had a range of zero and never came back)
+    {
+        const size_t n = (size_t)60000 * 6 + 77;
+        MockPlane p;
+        p.prepare(n, false, true);
+        unsigned long long seed = 12345;
+        std::vector<uint8_t> plane(n);
+        fill_plane(plane, 1, seed);
+        for (size_t i = 0; i < n; i++) p.at(i) = plane[i];
+        std::vector<uint16_t> hist((n / 60000 + 1) * 256, 0);
+        for (size_t i = 0; i < n; i++) hist[(i / 60000) * 256 + plane[i]]++;
+        const wrrc::PlaneWindow stale = p.io;
+        p.release();
+        p.prepare(n, false, true);  // the next call owns the stream; the coder below still holds the old handle
+        const unsigned long refused0 = g_refused.load();
+        wrrc::pool_configure(2, 4);
+        std::vector<uint8_t> out(wrrc::encode_bound_hist(hist.data(), n) + wrrc::kFailedBlockSlack);
+        wrrc::PlaneJob job;
+        wrrc::JobBatch batch;
+        job.kind = wrrc::PlaneJob::kEncode; job.src = nullptr; job.io = &stale; job.dst = out.data(); job.n = n; job.hist = hist.data();
+        if (!wrrc::pool_submit(&job, 1, &batch)) { printf("pool refused the job\n"); return 1; }
+        wrrc::pool_wait(&batch);
+        if (job.result != (size_t)-1 || g_refused.load() == refused0 || p.ho.next_first != 0) { printf("encoder on a refused window: result %zu\n", job.result); return 1; }
+        std::vector<uint8_t> stream(wrrc::encode_bound(n));
+        const size_t len = wrrc::encode_plane(plane.data(), n, stream.data(), nullptr);
+        MockPlane q;
+        q.prepare(n, true, false);
+        const wrrc::PlaneWindow stale_d = q.io;
+        q.release();
+        q.prepare(n, true, false);
+        wrrc::PlaneJob dj;
+        wrrc::JobBatch db;
+        dj.kind = wrrc::PlaneJob::kDecode; dj.src = stream.data(); dj.src_len = len; dj.dst = nullptr; dj.io = &stale_d; dj.n = n;
+        if (!wrrc::pool_submit(&dj, 1, &db)) { printf("pool refused the job\n"); return 1; }
+        wrrc::pool_wait(&db);
+        if (dj.result != (size_t)-1 || q.ho.next_first != 0 || q.ho.ended) { printf("decoder on a refused window: result %zu\n", dj.result); return 1; }
+        wrrc::pool_configure(0, 0);
     }
     (void)rng_state;
     printf("hand-over run OK\n");

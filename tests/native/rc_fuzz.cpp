@@ -126,22 +126,6 @@ int main() {
                 for (int k = 0; k < count; k++)
                     if (k != victim && (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k]))) { printf("vector: healthy stream disturbed\n"); return 1; }
             }
-            // the decoder's loop for planes of any statistics: the same planes, exact-size streams, damaged ones among healthy ones
-            for (int k = 0; k < count; k++) memset(back[k].data(), 0xEE, n[k]);
-            wrrc::decode_planes_vec(count, ip.data(), len.data(), bp.data(), n.data(), got.data(), nullptr, true);
-            for (int k = 0; k < count; k++)
-                if (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k])) { printf("any-statistics vector decode failed k=%d\n", k); return 1; }
-            for (int trial = 0; trial < 6; trial++) {
-                const int victim = (int)(rnd() % count);
-                std::vector<uint8_t> bad(enc[victim]);
-                if (trial < 2) bad.resize(bad.size() * (trial + 1) / 3);
-                else for (int j = 0; j < 16; j++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
-                std::vector<const uint8_t*> ip2(ip); std::vector<size_t> l2(len);
-                ip2[victim] = bad.data(); l2[victim] = bad.size();
-                wrrc::decode_planes_vec(count, ip2.data(), l2.data(), bp.data(), n.data(), got.data(), nullptr, true);
-                for (int k = 0; k < count; k++)
-                    if (k != victim && (got[k] != n[k] || memcmp(back[k].data(), p[k].data(), n[k]))) { printf("any-statistics vector: healthy stream disturbed\n"); return 1; }
-            }
             // the encoder's vector loop: exact-size output is not possible (the length is the result), so the
             // buffers have the documented bound and the bytes are compared
             std::vector<std::vector<uint8_t>> venc(count);
@@ -245,7 +229,7 @@ int main() {
                 ioe[k] = wrrc::PlaneWindow{Win::fn, &we[k]}; iod[k] = wrrc::PlaneWindow{Win::fn, &wd[k]};
                 pe[k] = &ioe[k]; pd[k] = &iod[k]; ip[k] = enc[k].data(); op[k] = wenc[k].data();
             }
-            for (int mode = 0; mode < 3; mode++) {  // 2: the decoder's loop for planes of any statistics
+            for (int mode = 0; mode < 2; mode++) {
                 if (mode == 0) wrrc::encode_planes(count, none.data(), n, op.data(), nullptr, wlen.data(), pe.data());
                 else if (!wrrc::encode_planes_vec(count, none.data(), ns.data(), op.data(), wlen.data(), pe.data())) continue;
                 for (int k = 0; k < count; k++) {
@@ -254,7 +238,7 @@ int main() {
                 }
                 for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
                 if (mode == 0) wrrc::decode_planes(count, ip.data(), len.data(), noned.data(), n, got.data(), pd.data());
-                else wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data(), mode == 2);
+                else wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data());
                 for (int k = 0; k < count; k++)
                     if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("windowed decode failed n=%zu mode=%d k=%d\n", n, mode, k); return 1; }
                 // a truncated and a corrupted stream among healthy ones
@@ -265,7 +249,7 @@ int main() {
                     ip2[1] = bad.data(); l2[1] = bad.size();
                     for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
                     if (mode == 0) wrrc::decode_planes(count, ip2.data(), l2.data(), noned.data(), n, got.data(), pd.data());
-                    else wrrc::decode_planes_vec(count, ip2.data(), l2.data(), noned.data(), ns.data(), got.data(), pd.data(), mode == 2);
+                    else wrrc::decode_planes_vec(count, ip2.data(), l2.data(), noned.data(), ns.data(), got.data(), pd.data());
                     for (int k = 0; k < count; k++)
                         if (k != 1 && (got[k] != n || memcmp(back[k].data(), p[k].data(), n))) { printf("windowed: healthy stream disturbed\n"); return 1; }
                 }
@@ -339,13 +323,115 @@ int main() {
                 wd[k] = Win{back[k].data(), n, (size_t)60000 * (1 + (k + trial) % 3), nullptr, 0, 0};
                 iod[k] = wrrc::PlaneWindow{Win::fn, &wd[k]}; pd[k] = &iod[k];
             }
-            for (int mode = 0; mode < 3; mode++) {
+            for (int mode = 0; mode < 2; mode++) {
                 for (int k = 0; k < count; k++) back[k].assign(n, 0xEE);
                 if (mode == 0) wrrc::decode_planes(count, ip.data(), len.data(), noned.data(), n, got.data(), pd.data());
-                else if (!wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data(), mode == 2)) continue;
+                else if (!wrrc::decode_planes_vec(count, ip.data(), len.data(), noned.data(), ns.data(), got.data(), pd.data())) continue;
                 for (int k = 0; k < count; k++)
                     if (got[k] != n || memcmp(back[k].data(), p[k].data(), n)) { printf("ragged blocks: windowed decode differs trial=%d mode=%d k=%d got=%zu\n", trial, mode, k, got[k]); return 1; }
             }
+        }
+    }
+    // An encoder whose block model is not the symbols' (the GPU delivers the histograms; a wrong one must end the stream, not
+    // the process): (a) histograms that do not add up to the block, (b) histograms that add up but count a symbol that turns
+    // up zero times -- the coder's range goes to zero there, which would feed the renormalisation loop for ever.  The stream
+    // must end with (size_t)-1 within the buffer (bound from those histograms + kFailedBlockSlack, exact size: ASan sees an
+    // overrun), and the healthy streams in the same loop must be untouched.  Scalar loops (pool without AVX-512 is not
+    // reachable here: encode_planes), the 16-lane loop through the pool.
+    {
+        const size_t n = (size_t)60000 * 6 + 4321;
+        const size_t nblk = n / 60000 + 1;
+        const int count = 20;   // more than a scalar loop holds: the pool's sessions run the 16-lane loop
+        std::vector<std::vector<uint8_t>> p(count), want(count), out(count);
+        std::vector<std::vector<uint16_t>> hist(count);
+        std::vector<size_t> wlen(count);
+        for (int k = 0; k < count; k++) {
+            p[k].resize(n);
+            for (size_t i = 0; i < n; i++) { unsigned r = rnd(); p[k][i] = k % 2 ? (uint8_t)((r & 7) ? 127 : 128 + (r >> 8 & 1)) : (uint8_t)(r & 255); }
+            hist[k].assign(nblk * 256, 0);
+            for (size_t i = 0; i < n; i++) hist[k][(i / 60000) * 256 + p[k][i]]++;
+            want[k].resize(wrrc::encode_bound(n));
+            wlen[k] = wrrc::encode_plane(p[k].data(), n, want[k].data(), hist[k].data());
+        }
+        for (int variant = 0; variant < 3; variant++) {
+            // the victims' histograms are damaged in block 2: (0) one count too many: the sum is off; (1) the count of a symbol
+            // that occurs moved to one that does not; (2) all counts moved to symbol 0 of a plane that holds other symbols
+            const int victims[3] = {1, 4, 17};
+            std::vector<std::vector<uint16_t>> h2(hist);
+            for (int v : victims) {
+                uint16_t* h = h2[v].data() + 2 * 256;
+                int present = -1, absent = -1;
+                for (int b = 255; b >= 0; b--) { if (h[b] && present < 0) present = b; if (!h[b] && absent < 0) absent = b; }
+                if (variant == 0) h[present]++;
+                else if (variant == 1 && absent >= 0) { h[absent] = h[present]; h[present] = 0; }
+                else { unsigned sum = 0; for (int b = 0; b < 256; b++) { sum += h[b]; h[b] = 0; } h[p[v][2 * 60000] == 0 ? 1 : 0] = (uint16_t)sum; }
+            }
+            for (int pass = 0; pass < 2; pass++) {  // 0: scalar interleaved loops on this thread, 1: the pool (16-lane sessions)
+                std::vector<uint8_t*> op(count);
+                std::vector<const uint8_t*> sp(count);
+                std::vector<const uint16_t*> hp(count);
+                std::vector<size_t> len(count, 0);
+                for (int k = 0; k < count; k++) {
+                    out[k].assign(wrrc::encode_bound_hist(h2[k].data(), n) + wrrc::kFailedBlockSlack, 0xEE);
+                    out[k].shrink_to_fit();
+                    op[k] = out[k].data(); sp[k] = p[k].data(); hp[k] = h2[k].data();
+                }
+                if (pass == 0) wrrc::encode_planes(count, sp.data(), n, op.data(), hp.data(), len.data());
+                else {
+                    wrrc::pool_configure(2, 4);
+                    std::vector<wrrc::PlaneJob> jobs(count);
+                    wrrc::JobBatch batch;
+                    for (int k = 0; k < count; k++) { jobs[k].kind = wrrc::PlaneJob::kEncode; jobs[k].src = sp[k]; jobs[k].n = n; jobs[k].dst = op[k]; jobs[k].hist = hp[k]; }
+                    if (!wrrc::pool_submit(jobs.data(), count, &batch)) { printf("pool refused\n"); return 1; }
+                    wrrc::pool_wait(&batch);
+                    for (int k = 0; k < count; k++) len[k] = jobs[k].result;
+                    wrrc::pool_configure(0, 0);
+                }
+                for (int k = 0; k < count; k++) {
+                    const bool victim = k == victims[0] || k == victims[1] || k == victims[2];
+                    if (victim) { if (len[k] != (size_t)-1) { printf("wrong histograms: stream %d did not fail (variant %d pass %d len %zu)\n", k, variant, pass, len[k]); return 1; } }
+                    else if (len[k] != wlen[k] || memcmp(out[k].data(), want[k].data(), wlen[k])) { printf("wrong histograms next door: healthy stream %d differs (variant %d pass %d)\n", k, variant, pass); return 1; }
+                }
+            }
+        }
+        // a refused window (PlaneWindow: null with a count): the encoder and the decoder give the stream up without touching a symbol
+        struct Refuser {
+            const uint8_t* plane; size_t allow, calls;  // serves windows below `allow`, refuses from there on
+            static uint8_t* fn(void* u, size_t first, size_t* count)
+            {
+                Refuser* r = (Refuser*)u;
+                r->calls++;
+                if (*count == 0 || first >= r->allow) return nullptr;
+                if (*count > 60000) *count = 60000;
+                return const_cast<uint8_t*>(r->plane) + first;
+            }
+        };
+        for (size_t allow : {(size_t)0, (size_t)120000}) {
+            Refuser r[3] = {{p[0].data(), allow, 0}, {p[1].data(), (size_t)-1, 0}, {p[2].data(), allow, 0}};
+            wrrc::PlaneWindow io[3] = {{Refuser::fn, &r[0]}, {Refuser::fn, &r[1]}, {Refuser::fn, &r[2]}};
+            const wrrc::PlaneWindow* pio[3] = {&io[0], &io[1], &io[2]};
+            const uint8_t* none[3] = {nullptr, nullptr, nullptr};
+            uint8_t* op[3];
+            const uint16_t* hp[3] = {hist[0].data(), hist[1].data(), hist[2].data()};
+            size_t len[3] = {0, 0, 0};
+            for (int k = 0; k < 3; k++) { out[k].assign(wrrc::encode_bound_hist(hist[k].data(), n) + wrrc::kFailedBlockSlack, 0xEE); op[k] = out[k].data(); }
+            wrrc::encode_planes(3, none, n, op, hp, len, pio);
+            if (len[0] != (size_t)-1 || len[2] != (size_t)-1 || len[1] != wlen[1] || memcmp(out[1].data(), want[1].data(), wlen[1])) {
+                printf("refused window: encoder lens %zu %zu %zu (allow %zu)\n", len[0], len[1], len[2], allow); return 1;
+            }
+            // decoder: the output window is refused
+            std::vector<uint8_t> sink(n);
+            struct DRef { uint8_t* out; size_t allow; static uint8_t* fn(void* u, size_t first, size_t* count) { DRef* d = (DRef*)u; if (*count == 0 || first >= d->allow) return nullptr; if (*count > 60000) *count = 60000; return d->out + first; } };
+            DRef d[2] = {{sink.data(), allow}, {sink.data(), (size_t)-1}};
+            wrrc::PlaneWindow dio[2] = {{DRef::fn, &d[0]}, {DRef::fn, &d[1]}};
+            const wrrc::PlaneWindow* pdio[2] = {&dio[0], &dio[1]};
+            const uint8_t* ins[2] = {want[0].data(), want[0].data()};
+            size_t lens2[2] = {wlen[0], wlen[0]}, got2[2] = {0, 0};
+            uint8_t* noned[2] = {nullptr, nullptr};
+            wrrc::decode_planes(1, ins, lens2, noned, n, got2, pdio);
+            if (got2[0] != (size_t)-1) { printf("refused window: decoder result %zu (allow %zu)\n", got2[0], allow); return 1; }
+            wrrc::decode_planes(1, ins + 1, lens2 + 1, noned, n, got2 + 1, pdio + 1);
+            if (got2[1] != n || memcmp(sink.data(), p[0].data(), n)) { printf("served windows: decoder failed\n"); return 1; }
         }
     }
     printf("range coder sanitizer run OK\n");

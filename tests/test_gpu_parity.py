@@ -557,7 +557,7 @@ with api.Context(0) as c:
         # host entry point (block histograms from the quantizer, planes through the windows)
         enc, _ = c.encode_host(f, tol)
         assert np.array_equal(enc["data"], want["data"]), (shape, tol, "host entry point")
-        # and back: the inverse transform takes up to four planes as they are (its finest level dequantizes on the way)
+        # and back
         out = np.empty_like(f); enc["data"] = enc["data"].copy()
         c.decode_host(out, enc)
         assert bits_equal(out, rec_want), (shape, tol, "reconstruction")
@@ -565,8 +565,8 @@ print("ok")
 '''
 
 
-@pytest.mark.parametrize("env", [{}, {"WR_TEST_ZERO_MIN_PATH": "1", "WR_INV_DQ": "1"}, {"WR_QUANT_INPLACE": "1"}, {"WR_PLANE_CHUNK_MB": "1", "WR_INV_DQ": "1"}],
-                         ids=["recompute", "rare_path_after_every_plane+inverse_from_planes", "in_place", "chunked_planes+inverse_from_planes"])
+@pytest.mark.parametrize("env", [{}, {"WR_TEST_ZERO_MIN_PATH": "1"}, {"WR_QUANT_INPLACE": "1"}, {"WR_PLANE_CHUNK_MB": "1"}],
+                         ids=["recompute", "rare_path_after_every_plane", "in_place", "chunked_planes"])
 def test_quantizer_without_a_residual_array(env, tmp_path):
     """The quantizer planes are cut from residuals that are recomputed from the coefficient array (k_quant_blk: 9 instead of
     17 bytes per element and plane), with the block histograms written on the way; the reference updates the array in place
@@ -574,10 +574,7 @@ def test_quantizer_without_a_residual_array(env, tmp_path):
     eight planes, odd sizes (tails of coding blocks and of 16-byte pieces), planes in 1 MiB chunks (blocks that straddle
     two), with the residual wanted and not; when the rare path that needs the residual in memory between two planes is taken
     after EVERY plane (sign of a zero minimum: residual_apply, then in place); and with the in-place kernels alone.
-    The way back likewise, with the accumulate pass (the default) and with WR_INV_DQ=1: the inverse transform's finest level
-    dequantizes its detail octants from the planes (up to four; k_inv_fused<true>, wrappers.cpp:513-514 in registers) --
-    planes as one array and in chunks, shapes whose z-planes divide a chunk and shapes that fall back to the accumulate
-    pass: reconstruction == oracle."""
+    The way back likewise (planes as one array and in chunks): reconstruction == oracle."""
     import os, subprocess, sys
     from util import ROOT
     script = tmp_path / "quant_paths.py"

@@ -284,15 +284,15 @@ def test_avx512_decoder_loop_same_symbols(oracle):
         pytest.skip("no AVX-512 on this CPU")
     for i, (d, g, p) in enumerate(zip(dec, got, planes)):
         assert g == p.size and np.array_equal(d, p), (i, p.size)
-    # the same planes, and noise planes of several shapes, through the 16-lane loop for planes of ANY statistics (low / help by
-    # vector division, table look-ups per lane): more planes than lanes, streams joining and leaving at block boundaries
+    # the same planes and noise planes of several shapes (every block of those falls back to the scalar loop of its lane):
+    # more planes than lanes, streams joining and leaving at block boundaries
     more = [rs.randint(0, 256, 300000 + 777 * k).astype(np.uint8) for k in range(6)]
     more += [np.clip(np.rint(rs.normal(128, 30, 360000)), 0, 255).astype(np.uint8), rs.randint(0, 2, 240000).astype(np.uint8) * 255,
              np.where(rs.random_sample(300000) < 0.5, 255, rs.randint(0, 256, 300000)).astype(np.uint8)]  # the largest symbol is frequent
     aplanes, aenc = planes + more, enc + [oracle.range_encode(p) for p in more]
-    dec, got = api.range_decode_vec(aenc, [p.size for p in aplanes], any_statistics=True)
+    dec, got = api.range_decode_vec(aenc, [p.size for p in aplanes])
     for i, (d, g, p) in enumerate(zip(dec, got, aplanes)):
-        assert g == p.size and np.array_equal(d, p), ("any-statistics loop", i, p.size)
+        assert g == p.size and np.array_equal(d, p), ("more planes than lanes", i, p.size)
     # the encoder's vector loop (candidate compares; rare other symbols through the lane's table; noise planes and
     # partial blocks through the scalar code of their stream)
     planes.append(np.where(rs.random_sample(300000) < 0.995, 255, rs.randint(0, 256, 300000)).astype(np.uint8))
@@ -300,8 +300,7 @@ def test_avx512_decoder_loop_same_symbols(oracle):
     venc = api.range_encode_vec(planes)
     for i, (a, b) in enumerate(zip(venc, enc)):
         assert np.array_equal(a, b), ("vector encode", i, planes[i].size)
-    # through the pool as well (dominant-symbol planes take the decoder's vector route there; the encoder's is
-    # opt-in with WR_VEC_ENCODE=1, read when the pool object is created: covered by the native harness)
+    # through the pool as well (dominant-symbol planes take the decoder's vector route there, every plane the encoder's)
     api.set_coder_pool(2, 4)
     try:
         penc = api.range_encode_pool(planes)
@@ -332,9 +331,9 @@ def test_windowed_symbol_access_same_bytes_as_oracle(oracle, n):
     api.set_coder_pool(3, 4)
     try:
         for chunk in (60000, 120000):
-            for mode in (0, 1, 2, 3):  # 3: the decoder's 16-lane loop for planes of any statistics (encoder as mode 2)
+            for mode in (0, 1, 2):
                 try:
-                    enc = api.range_encode_windowed(planes, chunk, min(mode, 2))
+                    enc = api.range_encode_windowed(planes, chunk, mode)
                     dec, got = api.range_decode_windowed(want, n, chunk, mode)
                 except api.WaveRangeError:
                     assert mode >= 2  # no AVX-512 on this CPU
@@ -417,32 +416,30 @@ for k in (1, 2, 3, 4, 5):   # sessions of 1 .. 5 streams that shrink to nothing 
         enc = api.range_encode_vec([planes[i] for i in sel])
         for i, e in zip(sel, enc):
             assert np.array_equal(e, want[i]), ("encode", k, i)
-        for any_stat in (False, True):
-            dec, got = api.range_decode_vec([want[i] for i in sel], [planes[i].size for i in sel], any_statistics=any_stat)
-            for i, d, g in zip(sel, dec, got):
-                assert g == planes[i].size and np.array_equal(d, planes[i]), ("decode", any_stat, k, i)
+        dec, got = api.range_decode_vec([want[i] for i in sel], [planes[i].size for i in sel])
+        for i, d, g in zip(sel, dec, got):
+            assert g == planes[i].size and np.array_equal(d, planes[i]), ("decode", k, i)
 n = 60000 * 2 + 54321
 ps = [p[:n] for p in planes[:3]]
 ws = [o.range_encode(p) for p in ps]
-for mode in (2, 3):         # the same through windows of two blocks (planes in device memory reach the coder that way)
-    enc = api.range_encode_windowed(ps, 120000, 2)
-    dec, got = api.range_decode_windowed(ws, n, 120000, mode)
-    for a, b, d, g, p in zip(enc, ws, dec, got, ps):
-        assert np.array_equal(a, b) and g == n and np.array_equal(d, p), ("windowed", mode)
+# the same through windows of two blocks (planes in device memory reach the coder that way)
+enc = api.range_encode_windowed(ps, 120000, 2)
+dec, got = api.range_decode_windowed(ws, n, 120000, 2)
+for a, b, d, g, p in zip(enc, ws, dec, got, ps):
+    assert np.array_equal(a, b) and g == n and np.array_equal(d, p), "windowed"
 print("ok")
 """
 
 
-@pytest.mark.parametrize("small_scalar", ["1", "0"])
-def test_small_vector_sessions_same_bytes(small_scalar):
+def test_small_vector_sessions_same_bytes():
     """A 16-lane session that is down to three streams or fewer runs them through the scalar interleaved loops
-    (wr_rangecoder.cpp, kSmallScalar; WR_VEC_SMALL_SCALAR=0: the vector loop whatever the count).  Both ways, in a child
-    process each (the switch is read once): sessions of 1-5 planes of all kinds and lengths -- the streams change loops in
-    mid-plane as their neighbours end -- must give the oracle's bytes and symbols, whole planes and windowed ones."""
+    (wr_rangecoder.cpp, VecEncGroup::step / VecDecGroup::prepare): sessions of 1-5 planes of all kinds and lengths -- the
+    streams change loops in mid-plane as their neighbours end -- must give the oracle's bytes and symbols, whole planes and
+    windowed ones."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, WR_VEC_SMALL_SCALAR=small_scalar)
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, "-c", SMALL_SESSIONS % root], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] in ("ok", "no AVX-512")
@@ -492,12 +489,12 @@ print("ok")
 """
 
 
-def test_two_decoder_groups_per_session_same_symbols():
-    """WR_VEC_DUAL=1 (opt-in): a vector decoder session holds two 16-lane groups whose symbol loops run interleaved
-    (wr_rangecoder_avx512.cpp, vec_decode_block2).  37 planes of all kinds through the measurement hook, the pool and
-    windows: the oracle's symbols, whatever group a stream lands in and whenever its neighbours end."""
+def test_more_decoder_streams_than_lanes_same_symbols():
+    """37 planes of all kinds through the 16-lane decoder's measurement hook, the pool and windows: more streams than a
+    session has lanes, so streams join as others end: the oracle's symbols, whatever lane a stream lands in and whenever
+    its neighbours end."""
     import sys
-    env = dict(os.environ, WR_VEC_DUAL="1")
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, "-c", DUAL_GROUPS % ROOT], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] in ("ok", "no AVX-512")

@@ -2,6 +2,7 @@
 arbitrary planes, stream anchors, transform round trips of the oracle on arbitrary small shapes."""
 import os
 
+import pytest
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
@@ -55,24 +56,26 @@ def test_bench_batch_sizing():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     fb = 1024 ** 3 * 8
+    big = 2048 * 2 ** 30  # (host memory given, so that the container's own free memory does not decide the test)
     # fields resident in HBM: two field buffers and the planes of two contexts per lane next to the three work-space slots
-    jobs, lim = bench.fit_jobs(5, 2, fb, 288 * 10 ** 9, host_mode=False)
+    jobs, lim = bench.fit_jobs(5, 2, fb, 288 * 10 ** 9, host_mode=False, host_mem=big)
     assert 1 <= jobs <= 5 and jobs <= max(1, lim["jobs_by_cpu"]) and jobs <= max(1, lim["jobs_by_hbm"])
     assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (3.0 * fb * 2))
-    # HBM nearly full: still one job, never zero
-    assert bench.fit_jobs(5, 2, fb, 40 * 10 ** 9, host_mode=False)[0] == 1
+    # HBM nearly full: refused with the arithmetic (round 4 clamped a negative budget to one job and let the rank die allocating)
+    with pytest.raises(bench.SizingRefused):
+        bench.fit_jobs(5, 2, fb, 40 * 10 ** 9, host_mode=False, host_mem=big)
     # host buffer to host buffer (the default): the planes of the fields in flight live in HBM -- a decoder's until its field is
     # done, an encoder's draining chunk by chunk: 0.75 of the two contexts' worst case per lane -- the host holds their coded
     # streams
-    jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9)
+    jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, host_mem=big)
     assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (0.75 * fb * 2)) and jobs <= max(1, lim["jobs_by_host_mem"])
     # two slots leave room for more lanes; tol 1e-16 (8 planes per field) for half as many
-    assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, nslots=2)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 2 * 2.2 * fb) // (0.75 * fb * 2))
-    assert bench.fit_jobs(64, 1, fb, 288 * 10 ** 9, planes_per_field=8)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (1.5 * fb))
+    assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, nslots=2, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 2 * 2.2 * fb) // (0.75 * fb * 2))
+    assert bench.fit_jobs(64, 1, fb, 288 * 10 ** 9, planes_per_field=8, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (1.5 * fb))
     # with the coder pool a lane is not a thread: two fields in flight per CPU (--fields-per-cpu)
-    jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True)
-    assert lim["jobs_by_cpu"] == int(2.0 * lim["cpus_per_rank"] // 2)
-    assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True, fields_per_cpu=1.5)[1]["jobs_by_cpu"] == int(1.5 * lim["cpus_per_rank"] // 2)
+    jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True, host_mem=big)
+    assert lim["jobs_by_cpu"] == max(1, int(2.0 * lim["cpus_per_rank"] // 2))
+    assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True, fields_per_cpu=1.5, host_mem=big)[1]["jobs_by_cpu"] == max(1, int(1.5 * lim["cpus_per_rank"] // 2))
     # where host memory is what holds the lanes back, consumed coded streams hand their pages back and more lanes fit
     plenty, tight = 2048 * 2 ** 30, 120 * 2 ** 30
     jobs, lim = bench.fit_jobs(16, 2, fb, 288 * 10 ** 9, pooled=True, host_mem=plenty)

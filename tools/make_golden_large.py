@@ -6,6 +6,9 @@ Run in the build container only: it calls the REFERENCE ITSELF (oracle/_ref/libw
 
     512^3  fp64, seed 12345, tol 1e-5 and 1e-7   (config 2; 1e-7 for a plane stream past 2^24 bytes)
     1024^3 fp64, seed 12345, tol 1e-3 and 1e-7   (config 3: what bench.py round-trips)
+    512^3 and 1024^3, seed 12345, tol 1e-16      (config 5's near-lossless tolerance: 8 planes, the NLAYMAX exit of
+                                                  src/core/wrappers.cpp:333 is taken before deps < tolabs :326-330)
+    512^3, seeds 12346..12352, tol 1e-5          (config 4: the fields of ranks 1..7 of an 8-rank run)
 
 and records what encoding_wrap returned (header scalars as hex doubles, plane lengths, SHA-256 of data_enc and of
 every plane stream) and the SHA-256 of what decoding_wrap reconstructed.  These are the first reference-held pins
@@ -13,7 +16,7 @@ where a plane stream is longer than the 24-bit bytecount trailer of rngcod13 can
 (src/rangecod/rangecod.c:254-276) and a plane has 17 896 coding blocks.  The fixture is data: inputs are re-generated
 from the seed (guarded by their SHA-256), outputs are hashes and scalars.
 
-    python tools/make_golden_large.py [512:1e-5 512:1e-7 1024:1e-3 1024:1e-7]     (default: all four; ~27 GiB, ~25 min)
+    python tools/make_golden_large.py [512:1e-5 512:1e-7 1024:1e-3 1024:1e-7 512:1e-5:12346 ...]   (SIZE:TOL[:SEED]; default: all; ~35 GiB, ~45 min)
 """
 import ctypes as C
 import hashlib
@@ -48,13 +51,13 @@ def fill_field(out, n, seed):
         out[z:z + step] = synth.field(n, n, n, seed, z, min(n, z + step))
 
 
-def run(impl_lib, which, n, tol):
+def run(impl_lib, which, n, tol, seed=SEED):
     """One encode + decode through `impl_lib` (the reference's or the oracle's entry points; `which` = 'ref' / 'oracle')
     with no field-sized copies beyond the one array the API works in place on."""
     dp, u8p, ulp = loader._dp, loader._u8p, loader._ulp
     fld = np.empty((n, n, n), dtype=np.float64)
-    fill_field(fld, n, SEED)
-    rec = {"n": n, "tol": repr(tol), "seed": SEED, "input_sha256": sha_of(fld), "input_absmax": float(np.abs(fld).max()).hex()}
+    fill_field(fld, n, seed)
+    rec = {"n": n, "tol": repr(tol), "seed": seed, "input_sha256": sha_of(fld), "input_absmax": float(np.abs(fld).max()).hex()}
     N = fld.size
     data = np.empty(loader.NLAYMAX * max(1024, N), dtype=np.uint8)  # setup_wr's ntot_enc_max; only coded bytes get touched
     cut = np.array([tol], dtype=np.float64)
@@ -87,7 +90,7 @@ def run(impl_lib, which, n, tol):
     t2 = time.time()
     rec["decoded_sha256"] = sha_of(fld)
     ref_in = np.empty((n, n, n), dtype=np.float64)
-    fill_field(ref_in, n, SEED)
+    fill_field(ref_in, n, seed)
     diff = 0.0
     for z in range(0, n, 32):
         diff = max(diff, float(np.abs(ref_in[z:z + 32] - fld[z:z + 32]).max()))
@@ -96,14 +99,16 @@ def run(impl_lib, which, n, tol):
     return rec
 
 
-def key(n, tol):
-    return "%d^3_tol%g" % (n, tol)
+def key(n, tol, seed=SEED):
+    """the bench's own field (seed 12345) has the short key; rank r of an N-rank run codes seed 12345 + r"""
+    return "%d^3_tol%g" % (n, tol) + ("" if seed == SEED else "_seed%d" % seed)
 
 
 def main():
-    cases = [(512, 1e-5), (512, 1e-7), (1024, 1e-3), (1024, 1e-7)]
+    cases = [(512, 1e-5, SEED), (512, 1e-7, SEED), (1024, 1e-3, SEED), (1024, 1e-7, SEED), (512, 1e-16, SEED), (1024, 1e-16, SEED)]
+    cases += [(512, 1e-5, SEED + r) for r in range(1, 8)]   # BASELINE configs[3]: the fields of ranks 1..7
     if len(sys.argv) > 1:
-        cases = [(int(a.split(":")[0]), float(a.split(":")[1])) for a in sys.argv[1:]]
+        cases = [(int(a.split(":")[0]), float(a.split(":")[1]), int((a.split(":") + [SEED])[2])) for a in sys.argv[1:]]
     ref = loader.Reference()
     out = {}
     if os.path.exists(OUT):
@@ -113,16 +118,16 @@ def main():
                      "written by tools/make_golden_large.py in the build container; hashes and scalars only")
     fd = os.dup(1)
     devnull = os.open(os.devnull, os.O_WRONLY)
-    for n, tol in cases:
+    for n, tol, seed in cases:
         sys.stdout.flush()
         os.dup2(devnull, 1)  # the reference prints progress lines from C++
         try:
-            rec = run(ref.lib, "ref", n, tol)
+            rec = run(ref.lib, "ref", n, tol, seed)
         finally:
             sys.stdout.flush()
             os.dup2(fd, 1)
-        out[key(n, tol)] = rec
-        print(key(n, tol), "nlay", rec["nlay"], "ntot_enc", rec["ntot_enc"], "lens", rec["len_enc_vec"], "linf_rel %.3g" % rec["linf_rel"], rec["seconds"], flush=True)
+        out[key(n, tol, seed)] = rec
+        print(key(n, tol, seed), "nlay", rec["nlay"], "ntot_enc", rec["ntot_enc"], "lens", rec["len_enc_vec"], "linf_rel %.3g" % rec["linf_rel"], rec["seconds"], flush=True)
         with open(OUT, "w") as fh:
             json.dump(out, fh, indent=1, sort_keys=True)
             fh.write("\n")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Quantizer plane kernel alone: wall time of wr_dev_quantize_plane on an n^3 field (kernel + residual min/max + one
-host round trip).  usage: prof_quant.py [n] [reps]   (WR_QUANT_DIRECT=1: the direct 2-byte-store form)"""
+host round trip).  usage: prof_quant.py [n] [reps]"""
 import os
 import sys
 import time

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """The encoder's 16-lane AVX-512 loop on one thread: noise planes (per-lane look-ups) and dominant-symbol planes (candidate
-compares), 4 / 8 / 16 planes, against the scalar loop of three.  WR_VEC_ENC_GATHER=1 selects the gather form of the
-look-ups.  CPU only.  usage: rc_enc.py [blocks per plane]"""
+compares), 4 / 8 / 16 planes, against the scalar loop of three.  CPU only.  usage: rc_enc.py [blocks per plane]"""
 import os
 import sys
 import time

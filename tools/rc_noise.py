@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The scalar decoder loop on noise planes (7.5 bits per symbol: no dominant symbols, no usable bucket table), 1-4 streams
-interleaved on one thread: the loop a third of the pool's worker-seconds goes to.  WR_RC_NOISE_LOOP=0 selects the general
-loop (two stream bytes and a 7-bit shift per renormalisation step) instead of the byte-aligned one, WR_RC_NOISE_ASM=0 the
-compiler's register allocation instead of the hand-written four-stream loop.  CPU only.
+interleaved on one thread: the loop a third of the pool's worker-seconds goes to.  (The general loop -- two stream bytes
+and a 7-bit shift per renormalisation step -- and the compiler's register allocation of the four-stream loop were measured
+against the byte-aligned, hand-allotted one in round 4: profiles/r04/e_rc_noise_*, m_rc_noise_*.)  CPU only.
 usage: rc_noise.py [blocks per plane]"""
 import os
 import sys
@@ -26,6 +26,4 @@ for k in range(1, kmax + 1):
         out, _ = api.range_decode_multi(streams[:k], n)
         best = min(best, time.time() - t)
     assert all(np.array_equal(o, p) for o, p in zip(out, planes[:k]))
-    print("noise planes, %d stream(s) in the loop: decode %6.1f Msym/s per thread (%5.1f per stream)  [WR_RC_NOISE_LOOP=%s]"
-          % (k, k * n / best / 1e6, n / best / 1e6, os.environ.get("WR_RC_NOISE_LOOP", "1")) +
-          (" [WR_RC_NOISE_ASM=0]" if os.environ.get("WR_RC_NOISE_ASM") == "0" else ""), flush=True)
+    print("noise planes, %d stream(s) in the loop: decode %6.1f Msym/s per thread (%5.1f per stream)" % (k, k * n / best / 1e6, n / best / 1e6), flush=True)

@@ -53,10 +53,11 @@ class EncInfo(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("total", C.c_double), ("gpu", C.c_double), ("transfer", C.c_double),
                 ("rangecoder", C.c_double), ("transform_ms", C.c_float), ("quant_ms", C.c_float),
-                ("minmax_ms", C.c_float), ("wait", C.c_double), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float)]
+                ("minmax_ms", C.c_float), ("wait", C.c_double), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float),
+                ("plane_coder_s", C.c_double * NLAYMAX)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k == "plane_coder_s" else getattr(self, k)) for k, _ in self._fields_}
 
 
 class WaveRangeError(RuntimeError):
@@ -138,7 +139,6 @@ def lib():
     L.wr_range_encode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_range_decode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_decode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
-    L.wr_range_decode_vec_any.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.wr_range_encode_vec.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
     L.wr_range_encode_windowed.argtypes = [C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
     L.wr_range_decode_windowed.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, C.c_size_t, _vp]
@@ -183,7 +183,7 @@ def set_device_slots(device, nslots):
 
 
 STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDLE_MS, STAT_POOL_STREAMS_MOVED = 0, 1, 2, 3, 4
-STAT_POOL_QUEUE_MS, STAT_PLANE_WAIT_MS, STAT_HANDOVER_ERRORS = 5, 6, 7
+STAT_POOL_QUEUE_MS, STAT_PLANE_WAIT_MS, STAT_HANDOVER_ERRORS, STAT_CLOCK_WARMUP_MS = 5, 6, 7, 8
 
 
 def stat(what):
@@ -192,9 +192,9 @@ def stat(what):
 
 def pool_loop_stats():
     """{loop kind: (worker seconds in block steps, stream-blocks advanced)} since the process started."""
-    sec, blk = (C.c_double * 5)(), (C.c_double * 5)()
+    sec, blk = (C.c_double * 4)(), (C.c_double * 4)()
     lib().wr_pool_loop_stats(sec, blk)
-    return {k: (sec[i], blk[i]) for i, k in enumerate(("scalar_encoder", "scalar_decoder", "vector_decoder", "vector_encoder", "vector_decoder_any"))}
+    return {k: (sec[i], blk[i]) for i, k in enumerate(("scalar_encoder", "scalar_decoder", "vector_decoder", "vector_encoder"))}
 
 
 def set_writeback_residual(on):
@@ -345,15 +345,13 @@ def range_encode_vec(planes):
     return [o[:lens[i]].copy() for i, o in enumerate(outs)]
 
 
-def range_decode_vec(streams, ns, any_statistics=False):
-    """Planes through the 16-lane AVX-512 decoder loop on this thread (raises on CPUs without AVX-512); any_statistics: the
-    loop for planes without dominant symbols (noise planes) instead of the candidate-compare loop."""
+def range_decode_vec(streams, ns):
+    """Planes through the 16-lane AVX-512 decoder loop on this thread (raises on CPUs without AVX-512)."""
     ss = [np.ascontiguousarray(s, dtype=np.uint8).ravel() for s in streams]
     k = len(ss)
     outs = [np.zeros(max(n, 1), dtype=np.uint8) for n in ns]
     got = (C.c_size_t * k)()
-    fn = lib().wr_range_decode_vec_any if any_statistics else lib().wr_range_decode_vec
-    _check(fn(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
+    _check(lib().wr_range_decode_vec(k, (C.c_void_p * k)(*[s.ctypes.data for s in ss]), (C.c_size_t * k)(*[s.size for s in ss]),
                                      (C.c_void_p * k)(*[o.ctypes.data for o in outs]), (C.c_size_t * k)(*ns), got))
     return [o[:n] for o, n in zip(outs, ns)], [got[i] for i in range(k)]
 

@@ -100,7 +100,7 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
     // When all four levels run on the fused kernels, those reduce min/max of the field and of the coefficient
     // array on the way (no stand-alone passes, one host round trip instead of two).  The transform then runs
     // before it is known whether the field is trivial; it is out of place, so nothing is lost if it is.
-    const size_t mm_records = (wtflag && use_fused(nx, ny, nz, kWavLvl) && !getenv("WR_NO_FUSED_MINMAX")) ? wrk::fused_minmax_records(nx, ny, nz) : 0;
+    const size_t mm_records = (wtflag && use_fused(nx, ny, nz, kWavLvl)) ? wrk::fused_minmax_records(nx, ny, nz) : 0;
     if (mm_records) {
         if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
         if (c->mm_records < mm_records) {
@@ -180,9 +180,9 @@ int encode_planes_core(wr_ctx* c, Slot* slot, double* d_fld, int nx, int ny, int
         if (d_plane->shift < 63 && (((uintptr_t)d_fld | (uintptr_t)d_plane->chunk[0]) & 15)) return fail(WR_ERR_ARG, "internal: chunked plane with an unaligned pointer");
         const bool blk = !local && (prev.n > 0 || ilay == 0) && wrk::quantize_plane_blk_ok(d_fld, *d_plane);
         const bool resid_upd = blk ? (s.last && c->keep_residual) : (!s.last || c->keep_residual);
-        // (WR_QUANT_HIST=0: the histograms by their own kernel behind the quantizer, for A/B measurements)
-        static const bool hist_fused = !(getenv("WR_QUANT_HIST") && !atoi(getenv("WR_QUANT_HIST")));
-        uint16_t* const d_hist = blk && hist_fused ? hist_buf(ilay) : nullptr;
+        // (the histograms by a kernel of their own behind the quantizer: 10.7 + 0.9 ms per field against 6.7,
+        // profiles/r04/x_quantizer_with_and_without_fused_histograms.txt)
+        uint16_t* const d_hist = blk ? hist_buf(ilay) : nullptr;
         launch_note(c, local ? "quant_local" : blk ? (resid_upd ? "quant_blk<1>" : "quant_blk<0>") : resid_upd ? "quant<1>" : "quant<0>", (int)ilay, d_fld, n,
                     c->d_partial, *d_plane);
         HIPCHK(hipEventRecord(c->ev_a, c->stream));
@@ -350,13 +350,14 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     // the sum of the bounds of planes 0 .. l-1, and the gaps are closed afterwards by moving the planes down in order (a few
     // megabytes each).  The coded bytes of a field then exist once in host memory, not twice (a 1e-7 field at 1024^3: 2 GB),
     // and the context keeps no per-plane output buffers.  A plane whose bound does not fit under `cap` takes the old way
-    // through c->enc_buf (only then can total <= cap < sum of bounds happen).
+    // through c->enc_buf (only then can total <= cap < sum of bounds happen).  The coder is told the bound (dst_limit): a
+    // stream that outgrows it was coded against histograms that are not its plane's and is given up, at most one block
+    // (wrrc::kFailedBlockSlack) late -- which is why that much room lies behind every plane's place.
     std::mutex place_mu;
     unsigned placed = 0;
     size_t est_off[WR_NLAYMAX + 1] = {0}, est_len[WR_NLAYMAX] = {0};
     uint8_t* plane_out[WR_NLAYMAX] = {nullptr};
     bool direct[WR_NLAYMAX] = {false};
-    static const bool direct_ok = !(getenv("WR_ENC_DIRECT") && !atoi(getenv("WR_ENC_DIRECT")));
     // (callable from the coder threads: the histograms of plane k and of the planes before it have been sent off)
     auto place_plane = [&](unsigned k) -> uint8_t* {
         std::lock_guard<std::mutex> lk(place_mu);
@@ -364,9 +365,9 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             if (xfer_wait(&c->x_plane[j]) != WR_OK) copy_failed[j] = 1;
             est_len[j] = copy_failed[j] ? wrrc::encode_bound(n) : wrrc::encode_bound_hist(c->h_hist + j * hist_per_plane, n);
             est_off[j + 1] = est_off[j] + est_len[j];
-            direct[j] = direct_ok && data_enc && est_off[j + 1] <= cap;
+            direct[j] = data_enc && est_off[j + 1] + wrrc::kFailedBlockSlack <= cap;
             if (direct[j]) plane_out[j] = data_enc + est_off[j];
-            else plane_out[j] = ensure_enc_buf(c, (int)j, est_len[j]) == WR_OK ? c->enc_buf[j] : nullptr;
+            else plane_out[j] = ensure_enc_buf(c, (int)j, est_len[j] + wrrc::kFailedBlockSlack) == WR_OK ? c->enc_buf[j] : nullptr;
             placed = j + 1;
         }
         return plane_out[k];
@@ -383,8 +384,12 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         uint8_t* outs[WR_NLAYMAX];
         const uint16_t* hs[WR_NLAYMAX];
         const wrrc::PlaneWindow* ios[WR_NLAYMAX];
-        for (unsigned l = l0; l < l1; l++) { syms[l - l0] = nullptr; outs[l - l0] = plane_out[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; ios[l - l0] = &c->ps[l].io; }
-        wrrc::encode_planes((int)(l1 - l0), syms, n, outs, hs, lens + l0, ios);
+        size_t limits[WR_NLAYMAX];
+        for (unsigned l = l0; l < l1; l++) {
+            syms[l - l0] = nullptr; outs[l - l0] = plane_out[l]; hs[l - l0] = c->h_hist + l * hist_per_plane; ios[l - l0] = &c->ps[l].io;
+            limits[l - l0] = est_len[l];
+        }
+        wrrc::encode_planes((int)(l1 - l0), syms, n, outs, hs, lens + l0, ios, limits);
         for (unsigned l = l0; l < l1; l++) coder_s[l] = now() - t;
         sem.release();
     };
@@ -436,7 +441,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             handed |= 1u << k;
             wrrc::PlaneJob& j = jobs[k];
             j.kind = wrrc::PlaneJob::kEncode;
-            j.src = nullptr; j.io = &c->ps[k].io; j.dst = dst; j.n = n; j.hist = c->h_hist + k * hist_per_plane;
+            j.src = nullptr; j.io = &c->ps[k].io; j.dst = dst; j.n = n; j.hist = c->h_hist + k * hist_per_plane; j.dst_limit = est_len[k];
             if (wrrc::pool_submit(&j, 1, &batch)) pool_mask |= 1u << k;
             else workers.v.emplace_back(code_group, k, k + 1);  // the pool was stopped meanwhile: a thread of this call codes the plane
         };
@@ -472,7 +477,6 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         };
         {
             // ---- stage "kernels"
-            StageGate gate(pool);
             cu.lock();
             clock_warmup(c, n);
             rc = encode_planes_core(c, slot.get(), d_fld, nx, ny, nz, wtflag, cut, plane_buf, hist_buf, info, &local, after_quant, plane_ready, &resid);
@@ -521,6 +525,8 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
     if (rc) return rc;
     for (unsigned l = 0; l < info->nlay; l++) {
         if (copy_failed[l] || c->ps[l].err) return fail(WR_ERR_HIP, "download of plane " + std::to_string(l) + " failed");
+        if (lens[l] == (size_t)-1)  // (a refused window sets ps[l].err as well; what is left: histograms that are not the plane's)
+            return fail(WR_ERR_HIP, "internal: the coder gave plane " + std::to_string(l) + " up (its block histograms are not its symbols')");
         local.d2h_ms += (float)(c->x_plane[l].ms + c->ps[l].copy_ms);
         if (verbose()) logs[l] = plane_log(c, (int)l, n, info, true, lens[l]);  // wrappers.cpp:401-409, 430
     }
@@ -531,6 +537,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         offs[l] = total;
         total += lens[l];
         info->len_enc_vec[l] = lens[l];
+        local.plane_coder_s[l] = coder_s[l];
         if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
     }
     for (unsigned l = 0; l < info->nlay; l++)  // (cannot happen: the bound is rigorous; if it did, a neighbour's bytes are gone)
@@ -673,6 +680,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         int bad = -1;
         for (int l = 0; l < nlay && host_half; l++) {
             if (got[l] != n) bad = l;
+            local.plane_coder_s[l] = coder_s[l];
             if (coder_s[l] > local.rangecoder) local.rangecoder = coder_s[l];
         }
         if (bad >= 0) return fail(WR_ERR_STREAM, "plane " + std::to_string(bad) + ": stream does not decode to nx*ny*nz symbols");
@@ -710,7 +718,6 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         double* d_fld = fld.host ? slot->field : fld.dev;
         {
             // ---- stage "kernels"
-            StageGate gate(pool);
             StageLock cu(pool->cu_mu);
             clock_warmup(c, n);
             rc = inverse_from_planes(c, slot.get(), d_fld, nx, ny, nz, (int)info->wlev, p);

@@ -27,13 +27,6 @@ int wr_range_decode_vec(int count, const unsigned char* const* in, const size_t*
     return WR_OK;
 }
 
-int wr_range_decode_vec_any(int count, const unsigned char* const* in, const size_t* len, unsigned char* const* sym, const size_t* n,
-                            size_t* produced)
-{
-    if (!wrrc::decode_planes_vec(count, in, len, sym, n, produced, nullptr, true)) return fail(WR_ERR_UNSUPPORTED, "this CPU has no AVX-512");
-    return WR_OK;
-}
-
 int wr_range_encode_vec(int count, const unsigned char* const* sym, const size_t* n, unsigned char* const* out, size_t* lens)
 {
     if (!wrrc::encode_planes_vec(count, sym, n, out, lens)) return fail(WR_ERR_UNSUPPORTED, "this CPU has no AVX-512");
@@ -147,7 +140,7 @@ int wr_range_decode_windowed(int mode, int count, const unsigned char* const* in
     std::vector<unsigned char*> none((size_t)count, nullptr);
     for (int k = 0; k < count; k++) { w[k].out = sym[k]; w[k].init(n, chunk, true); io[k] = &w[k].io; }
     if (mode == 0) wrrc::decode_planes(count, in, len, none.data(), n, produced, io.data());
-    else if (mode == 2 || mode == 3) { if (!wrrc::decode_planes_vec(count, in, len, none.data(), ns.data(), produced, io.data(), mode == 3)) return fail(WR_ERR_UNSUPPORTED, "this CPU has no AVX-512"); }
+    else if (mode == 2) { if (!wrrc::decode_planes_vec(count, in, len, none.data(), ns.data(), produced, io.data())) return fail(WR_ERR_UNSUPPORTED, "this CPU has no AVX-512"); }
     else {
         if (wrrc::pool_threads() < 1) return fail(WR_ERR_ARG, "the coder pool is not running (wr_set_coder_pool)");
         std::vector<wrrc::PlaneJob> jobs((size_t)count);

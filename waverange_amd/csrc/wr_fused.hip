@@ -479,22 +479,15 @@ __device__ inline void lift_inv_four(const double s[7], const double d[8], doubl
 }
 }  // namespace
 
-// DQ: the detail octants are not read from a coefficient array but dequantized on the way from the bit planes themselves
-// (wrappers.cpp:480, 513-514: fld = 0; fld += q_l * deps_l + minval_l, l in order -- the same sums, in registers), so the
-// finest level, 7/8 of all coefficients, never exists in memory as doubles: the decoder's accumulate pass over the whole
-// array (8 B written and 8 B read back per element) shrinks to the coarse corner box the other levels read.
-constexpr int kInvDqPlanes = 4;
-struct InvDq {
-    PlaneRef q[kInvDqPlanes];
-    double deps[kInvDqPlanes], minval[kInvDqPlanes];
-    int nlay;
-};
-template <bool DQ>
+// (A form of this kernel that dequantized the finest level's detail octants from the bit planes on the way -- no accumulate
+// pass over the whole array, 16 GB of traffic less per decode -- was built in round 4, bit-exact, and measured EQUAL: 6.6 ms
+// against 2.5 + 4.2 = 6.7 ms, its ~480 extra vector instructions per thread and z step sitting in the z phase of a kernel
+// whose eight waves per CU move through their phases together.  Removed in round 5: profiles/r04/j_inverse_from_planes.txt.)
 __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
-    const double* __restrict__ src, size_t s_sy, size_t s_sz,  // coefficient array (detail octants); DQ: its strides only
+    const double* __restrict__ src, size_t s_sy, size_t s_sz,  // coefficient array (detail octants)
     const double* __restrict__ low, size_t l_sy, size_t l_sz,  // low-pass octant (previous level's output)
     double* __restrict__ out, size_t o_sy, size_t o_sz,        // reconstructed box of this level
-    int n1, int n2, int n3, int zps, InvDq dq
+    int n1, int n2, int n3, int zps
 #ifdef WR_STAMP
     , unsigned long long* __restrict__ stamp_out
 #endif
@@ -538,54 +531,19 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     }
     // the coefficient chunks of z-pair t go straight into registers: the z step is the only reader,
     // it runs first in a step, and the registers are free again for the next pair right after it.
-    // Slot 0 holds low-pass chunks only (INTHR <= HY * CROW), slot 1 some, the others none: the low-pass octant is read
-    // as doubles in either form of the kernel.
-    static_assert(INTHR <= HY * CROW && 2 * INTHR >= HY * CROW, "which chunk slots hold low-pass chunks");
-    double2 rl[DQ ? 2 : KCI], rh[DQ ? 1 : KCI];
-    unsigned short ul[DQ ? kInvDqPlanes : 1][KCI], uh[DQ ? kInvDqPlanes : 1][KCI];  // DQ: two plane bytes per chunk and plane
+    double2 rl[KCI], rh[KCI];
     auto fetch = [&](int t) {
         const double* pll = low + (size_t)t * l_sz;
-        if (DQ) {
-            // (a z-plane of a bit plane lies in ONE of its chunks: the host checks that nx * ny divides the chunk size)
-            const size_t zl = (size_t)t * s_sz, zh = (size_t)(m3 + t) * s_sz;
+        const double* pl = src + (size_t)t * s_sz;
+        const double* ph = src + (size_t)(m3 + t) * s_sz;
 #pragma unroll
-            for (int l = 0; l < kInvDqPlanes; l++) {
-                if (l < dq.nlay) {
-                    const uint8_t* bl = dq.q[l].at(zl);
-                    const uint8_t* bh = dq.q[l].at(zh);
-#pragma unroll
-                    for (int k = 0; k < KCI; k++) {
-                        if ((valid_mask >> k) & 1) {
-                            if (k > 0) ul[l][k] = *reinterpret_cast<const unsigned short*>(bl + offL[k]);  // (a low-pass chunk of slot 1: any valid address)
-                            uh[l][k] = *reinterpret_cast<const unsigned short*>(bh + offH[k]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-                if (((valid_mask & lll_mask) >> k) & 1) rl[k] = *reinterpret_cast<const double2*>(pll + offL[k]);
-        } else {
-            const double* pl = src + (size_t)t * s_sz;
-            const double* ph = src + (size_t)(m3 + t) * s_sz;
-#pragma unroll
-            for (int k = 0; k < KCI; k++) {
-                if ((valid_mask >> k) & 1) {
-                    rl[k] = *reinterpret_cast<const double2*>((((lll_mask >> k) & 1) ? pll : pl) + offL[k]);
-                    rh[k] = *reinterpret_cast<const double2*>(ph + offH[k]);
-                }
+        for (int k = 0; k < KCI; k++) {
+            if ((valid_mask >> k) & 1) {
+                rl[k] = *reinterpret_cast<const double2*>((((lll_mask >> k) & 1) ? pll : pl) + offL[k]);
+                rh[k] = *reinterpret_cast<const double2*>(ph + offH[k]);
             }
         }
     };
-    // DQ: element e of a chunk from its bytes, the decoder's sum in plane order (wrappers.cpp:513-514, k_dequant)
-    auto dequant = [&](const unsigned short (&u)[DQ ? kInvDqPlanes : 1][KCI], int k, int e) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < kInvDqPlanes; l++)
-            if (DQ && l < dq.nlay) a = a + ((double)((u[l][k] >> (8 * e)) & 0xff) * dq.deps[l] + dq.minval[l]);
-        return a;
-    };
-
     const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
     const int iL = m1 - 1 - px0;
     double* ybw = yb + w * YWAVE;  // this wave's four rows of [xlow 68 | xhigh 68] (yrow_off)
@@ -692,19 +650,7 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                 // 329,335) with one block-uniform select on an operand.  Steps outside [0, m3) of the
                 // pipeline's fill and drain compute on stale operands; nothing they produce reaches an
                 // emitted plane (the selects below cut exactly those dependencies).
-                double lo[2], hi[2];
-                if (DQ) {
-                    const bool lll = (lll_mask >> k) & 1;  // (slot 0: every lane, slot 1: some, else none)
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        hi[e] = dequant(uh, k, e);
-                        if (k == 0) lo[e] = e ? rl[0].y : rl[0].x;
-                        else if (k == 1) { const double dv = dequant(ul, k, e); lo[e] = lll ? (e ? rl[1].y : rl[1].x) : dv; }
-                        else lo[e] = dequant(ul, k, e);
-                    }
-                } else {
-                    lo[0] = rl[k].x; lo[1] = rl[k].y; hi[0] = rh[k].x; hi[1] = rh[k].y;
-                }
+                const double lo[2] = {rl[k].x, rl[k].y}, hi[2] = {rh[k].x, rh[k].y};
                 // the y pass's opening scale: y-low quadrants are its s (* 1/zeta), y-high quadrants its d (* zeta)
                 const double sc = (k < KH) ? WR_IZETA : WR_ZETA;
                 double ev[2], od[2];
@@ -779,7 +725,6 @@ static int pick_zps(int tiles, int m3, int per_round)
     // rounds of 256 workgroups; every segment pays 4 extra steps (2 warm-up + 2 drain).
     // Measured at 1024^3 (level 0, 256 tiles): one round of 512 z-pairs 4.57 ms, 2 x 256 the same,
     // 4 x 128 4.72 ms, 8 x 64 4.69 ms.
-    if (const char* e = getenv("WR_ZPS")) { int v = atoi(e); if (v > 0) return v < m3 ? v : m3; }
     int best = m3;
     double best_cost = 1e300;
     for (int segs = 1; segs <= m3; segs++) {
@@ -870,8 +815,7 @@ const char* fused_prepare()
         {(const void*)k_fwd_fused<false, false>, "k_fwd_fused<false,false>", (int)LDS_BYTES},
         {(const void*)k_fwd_fused<true, true>, "k_fwd_fused<true,true>", (int)LDS_BYTES},
         {(const void*)k_fwd_fused<false, true>, "k_fwd_fused<false,true>", (int)LDS_BYTES},
-        {(const void*)k_inv_fused<false>, "k_inv_fused<false>", (int)LDS_INV},
-        {(const void*)k_inv_fused<true>, "k_inv_fused<true>", (int)LDS_INV}};
+        {(const void*)k_inv_fused, "k_inv_fused", (int)LDS_INV}};
     for (const auto& k : ks) {
         const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
         if (e != hipSuccess) {
@@ -938,55 +882,12 @@ void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int n
     for (int k = nfused; k < 4; k++) transform_level(dst, src, nx, ny, nz, k, false, st);
 }
 
-// The decoder's sums over the coarse corner box only ((nx/2) x (ny/2) x (nz/2): what the levels above the finest read as
-// doubles), one workgroup per row of the box; the rest of the coefficient array is never written (k_inv_fused<true>).
-__global__ __launch_bounds__(256) void k_dequant_corner(double* __restrict__ acc, int nx, int ny, int m1, int m2, DequantParams p)
-{
-    const int y = blockIdx.x % m2, z = blockIdx.x / m2;
-    const size_t row = ((size_t)z * ny + y) * nx;  // (a row lies in one chunk of every plane: see inv_dq_ok)
-    for (int x = threadIdx.x; x < m1; x += 256) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < 8; l++)
-            if (l < p.nlay) a = a + ((double)p.q[l].at(row)[x] * p.deps[l] + p.minval[l]);
-        acc[row + x] = a;
-    }
-}
-
-// The inverse can take the planes themselves (transform_inv_fused's dq) when the finest level runs fused, there are at most
-// four planes (their bytes wait in registers for a step: tol 1e-16's eight take the accumulate pass), and a z-plane of the
-// field never straddles two chunks of a plane (sizes that are powers of two; other sizes take the accumulate pass).
-bool inv_dq_ok(const DequantParams& p, int nx, int ny, int nz)
-{
-    // Opt-in (WR_INV_DQ=1).  Measured at 1024^3, four planes, same box (profiles/r04/j_inverse_from_planes.txt): 6.6 ms for the
-    // decoder's kernel stage this way against 2.5 + 4.2 = 6.7 ms with the accumulate pass -- 16 GB of traffic less, and the
-    // time it saved spent again inside the finest level: the dequantization is ~480 vector instructions per thread and z step
-    // on top of ~1100, in the z phase of a kernel whose eight waves per CU move through their phases together, so it is not
-    // hidden behind anybody's memory waits.
-    static const bool on = getenv("WR_INV_DQ") && atoi(getenv("WR_INV_DQ"));
-    if (!on || p.nlay < 1 || p.nlay > kInvDqPlanes || fused_levels(nx, ny, nz, true) < 1) return false;
-    const size_t plane = (size_t)nx * ny;
-    for (int l = 0; l < p.nlay; l++) {
-        if (p.q[l].shift >= 63) continue;  // one array
-        if ((((size_t)1 << p.q[l].shift) % plane) != 0) return false;
-    }
-    return true;
-}
-
-// dq == nullptr: src holds the coefficient array.  dq != nullptr (inv_dq_ok): src is scratch -- only its coarse corner box
-// is filled here, from the planes; the finest level dequantizes its detail octants on the way.
-void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st, const DequantParams* dq)
+// src holds the coefficient array; the reconstruction lands in dst
+void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st)
 {
     (void)fused_prepare();
     const size_t f_sy = (size_t)nx, f_sz = (size_t)nx * ny;
     const int nfused = fused_levels(nx, ny, nz, true);
-    InvDq idq;
-    memset(&idq, 0, sizeof idq);
-    if (dq) {
-        hipLaunchKernelGGL(k_dequant_corner, dim3((unsigned)((nz / 2) * (ny / 2))), dim3(256), 0, st, src, nx, ny, nx / 2, ny / 2, *dq);
-        for (int l = 0; l < dq->nlay && l < kInvDqPlanes; l++) { idq.q[l] = dq->q[l]; idq.deps[l] = dq->deps[l]; idq.minval[l] = dq->minval[l]; }
-        idq.nlay = dq->nlay;
-    }
     // compact reconstruction buffers: C1 = (n/2)^3, C2 = (n/4)^3, C3 = (n/8)^3, laid out as in the forward pass
     double* cbuf[4] = {nullptr, lowbuf, nullptr, nullptr};
     cbuf[2] = cbuf[1] + (size_t)(nx >> 1) * (ny >> 1) * (nz >> 1);
@@ -1010,17 +911,12 @@ void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int n
         const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + ITYP - 1) / ITYP);
         const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_INV));
         dim3 grid(tiles, (m3 + zps - 1) / zps);
-        const bool from_planes = dq && l == 0;
 #ifdef WR_STAMP
-        hipLaunchKernelGGL(k_inv_fused<false>, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
-                           n2, n3, zps, idq, l == 0 ? g_stamp_buf : nullptr);
+        hipLaunchKernelGGL(k_inv_fused, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
+                           n2, n3, zps, l == 0 ? g_stamp_buf : nullptr);
 #else
-        if (from_planes)
-            hipLaunchKernelGGL(k_inv_fused<true>, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
-                               n2, n3, zps, idq);
-        else
-            hipLaunchKernelGGL(k_inv_fused<false>, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
-                               n2, n3, zps, idq);
+        hipLaunchKernelGGL(k_inv_fused, grid, dim3(INTHR), LDS_INV, st, src, f_sy, f_sz, lo, lo_sy, lo_sz, o, o_sy, o_sz, n1,
+                           n2, n3, zps);
 #endif
     }
 }

@@ -41,7 +41,7 @@ constexpr double kWavAccCoef = 1.75;
 constexpr unsigned long kSafetyBufferFactor = 1;
 constexpr int kMaxDevices = 64;
 
-extern std::atomic<unsigned long> g_stat[8];  // see wr_stat()
+extern std::atomic<unsigned long> g_stat[12];  // see wr_stat()
 std::string& last_error();            // this thread's message (wr_last_error)
 int coder_threads();                  // wr_set_threads / WR_THREADS, default one per plane
 int encoder_threads();
@@ -129,7 +129,7 @@ private:
         for (const Buf& b : idle) { allocated -= b.bytes; wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] -= b.bytes; (void)hipFree(b.p); }
         idle.clear();
     }
-    void* device_alloc(size_t bytes);
+    void* device_alloc(size_t bytes, bool others_hold_planes);
 };
 
 struct DevPool {
@@ -139,12 +139,6 @@ struct DevPool {
     int users = 0;
     hipStream_t up = nullptr, down = nullptr;  // pageable fallback copies only
     std::mutex up_mu, cu_mu, down_mu;
-    // Measurement hook, off by default: with WR_STAGE_BATCH_MS=k a kernel stage that finds the GPU idle while many host calls
-    // are in flight on it (8 or more: a pipeline, not a lone caller) waits up to k ms for a second stage to show up, so that
-    // the two run back to back and the second one finds the shader clock up (stage_gather)
-    std::mutex gate_mu; std::condition_variable gate_cv;
-    int gate_waiting = 0;
-    double gate_last_end = 0;
     std::atomic<double> last_stage_end{0};  // when the last kernel stage of a host call gave up cu_mu (clock_warmup)
     std::atomic<int> active_calls{0};  // wr_encode_* / wr_decode_* calls inside the library on this device
     DevPlanes planes;
@@ -192,7 +186,7 @@ struct wr_ctx {
         wrk::PlaneRef ref{};
         // Hand-over check (wr_handover.h): every plane_prepare / plane_release starts a new generation of the plane, the
         // handle the coder gets (io.user) is a ticket for one generation, and a window request that is stale, out of
-        // order or not alone in the stream gets a scratch window instead of the ring and the chunk table
+        // order or not alone in the stream gets no window at all: its coder gives the stream up, the call it belongs to fails
         // (wr_pipeline.cpp: refused_window)
         struct Ticket { PlaneStream* s = nullptr; uint64_t gen = 0; };
         Ticket tickets[8];
@@ -371,15 +365,6 @@ struct ActiveCall {  // RAII: a codec call is inside the library
     ~ActiveCall() { p->active_calls--; }
     ActiveCall(const ActiveCall&) = delete;
     ActiveCall& operator=(const ActiveCall&) = delete;
-};
-void stage_gather(DevPool* p);     // before a host call's kernel stage takes cu_mu
-void stage_done(DevPool* p);       // after it has let go of it
-struct StageGate {  // RAII pair of the two: an exception between them must not leave the gate's count raised
-    DevPool* p;
-    explicit StageGate(DevPool* pool) : p(pool) { stage_gather(p); }
-    ~StageGate() { stage_done(p); }
-    StageGate(const StageGate&) = delete;
-    StageGate& operator=(const StageGate&) = delete;
 };
 void clock_warmup(wr_ctx* c, size_t n);  // first thing in a host call's kernel stage (cu_mu held); n: elements of the field
 int check_dims(int nx, int ny, int nz, const void* dev_ptr);

@@ -136,9 +136,5 @@ const char* fused_prepare();
 size_t fused_minmax_records(int nx, int ny, int nz);
 void transform_fwd_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st,
                          double* mm_partial = nullptr, double* mm_result = nullptr);
-// dq (only when inv_dq_ok says so): the planes themselves instead of a coefficient array -- src is then scratch, its coarse
-// corner box is filled from the planes here and the finest level dequantizes its detail octants on the way (no accumulate
-// pass over the whole array: dequant_accum is not called)
-bool inv_dq_ok(const DequantParams& p, int nx, int ny, int nz);
-void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st, const DequantParams* dq = nullptr);
+void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int ny, int nz, hipStream_t st);
 }  // namespace wrk

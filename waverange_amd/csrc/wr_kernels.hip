@@ -481,14 +481,13 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_lds(double* __restrict
 void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, double minval, const PlaneRef& q,
                     bool write_resid, double* partial, double* result, hipStream_t st)
 {
-    static const bool lds_ok = !(getenv("WR_QUANT_DIRECT") && atoi(getenv("WR_QUANT_DIRECT")));
     const bool aligned = (((uintptr_t)x | (uintptr_t)q.chunk[0]) & 15) == 0;
     const bool chunked = q.shift < 63;  // (chunks are device allocations: aligned; the direct form below wants one array)
     if (chunked && !aligned) {  // the callers check this (wr_codec.cpp); the direct form would run past the first chunk
         fprintf(stderr, "libwaverange_amd: internal error: chunked plane with unaligned pointers (x=%p chunk0=%p)\n", (void*)x, (void*)q.chunk[0]);
         abort();
     }
-    const size_t nchunks = ((lds_ok || chunked) && aligned) ? n / Q_CHUNK : 0;
+    const size_t nchunks = aligned ? n / Q_CHUNK : 0;
     int g1 = 0;
     if (nchunks) {
         g1 = (int)(nchunks < (size_t)WR_RED_BLOCKS / 2 ? nchunks : (size_t)WR_RED_BLOCKS / 2);
@@ -523,6 +522,16 @@ void quantize_plane(double* x, size_t n, double aopt, double bopt, double deps, 
 // =====================================================================================
 constexpr int QB = 60000;
 constexpr int QW = 1024;  // elements a wave takes at a time: 8 x 16-byte loads per lane, 16 plane bytes per lane
+// Between one wave's LDS stores and its own loads of the same bytes through another type (wave-private staging, no other
+// wave involved): the hardware runs a wave's LDS instructions in order, so no s_barrier is needed -- but the compiler must
+// be told that the type-punned loads depend on the stores.  A wavefront-scope release/acquire fence pair and the wave barrier
+// (a scheduling barrier, zero instructions) say exactly that and nothing more.
+__device__ inline void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <bool WRITE, bool MM, bool HIST>
 __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict__ x, size_t n, QuantPrev prev, double aopt, double bopt,
                                                               double deps, double minval, PlaneRef q, uint16_t* __restrict__ hist,
@@ -607,7 +616,9 @@ __global__ __launch_bounds__(WR_RED_THREADS) void k_quant_blk(double* __restrict
                 }
             }
             const size_t i = g0 + 16 * (size_t)lane;  // this lane's 16 symbols
+            wave_lds_fence();  // the byte pairs above -> the 16-byte pieces below
             const uint4 wq = reinterpret_cast<const uint4*>(&sq[w][0])[lane];
+            wave_lds_fence();  // ... and the next round's stores stay behind these loads
             if (i < b1) {
                 uint8_t* const dstq = i < edge ? p0 + (i - b0) : p1 + (i - edge);
                 const int cnt = (b1 - i < 16) ? (int)(b1 - i) : 16;
@@ -673,7 +684,7 @@ void quantize_plane_blk(double* x, size_t n, const QuantPrev& prev, double aopt,
 {
     const size_t nb = n / QB + 1;
     // one round of resident workgroups (8 per CU at most), each with a dozen blocks or more to stream through
-    static const size_t gmax = []() { const char* e = getenv("WR_QUANT_GRID"); const long v = e ? atol(e) : 0; return v >= 1 && v <= WR_RED_BLOCKS ? (size_t)v : (size_t)WR_RED_BLOCKS / 2; }();
+    constexpr size_t gmax = (size_t)WR_RED_BLOCKS / 2;
     const int g = (int)(nb < gmax ? nb : gmax);
 #define WR_QB_LAUNCH(W, M, H) hipLaunchKernelGGL((k_quant_blk<W, M, H>), dim3(g), dim3(WR_RED_THREADS), 0, st, x, n, prev, aopt, bopt, deps, minval, q, hist, partial)
     if (hist) {
@@ -779,6 +790,7 @@ __global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, s
 #pragma unroll
         for (int l = 0; l < 8; l++)
             if (l < p.nlay) sq[w][l][lane] = reinterpret_cast<const uint4*>(p.q[l].at(base))[lane];
+        wave_lds_fence();  // the 16-byte pieces above -> the byte pairs below (same wave; see k_quant_blk)
         double2* a2 = reinterpret_cast<double2*>(acc + base);
 #pragma unroll
         for (int j = 0; j < DQW / 128; j++) {
@@ -793,6 +805,7 @@ __global__ __launch_bounds__(256) void k_dequant_lds(double* __restrict__ acc, s
             }
             a2[j * 64 + lane] = a;
         }
+        wave_lds_fence();  // the next round's stores stay behind this round's loads
     }
 }
 

@@ -23,7 +23,7 @@ std::string& last_error() { return g_err; }
 std::atomic<int> g_verbose{-1};      // -1: not initialised from the environment yet
 std::atomic<int> g_threads{-1};      // -1: not initialised from the environment yet (WR_THREADS, default one per plane)
 std::atomic<int> g_enc_threads{0};   // 0: same as g_threads (wr_set_encoder_threads)
-std::atomic<unsigned long> g_stat[8];  // see wr_stat()
+std::atomic<unsigned long> g_stat[12];  // see wr_stat()
 std::atomic<int> g_writeback{-1};    // drop-in encoding_wrap leaves the residual in fld_1d (-1: from WR_WRITEBACK_RESIDUAL, default 1)
 
 int coder_threads()
@@ -110,10 +110,13 @@ bool DevPlanes::alloc_fails_now()
     return k >= hook.first && k < hook.first + hook.count;
 }
 
-void* DevPlanes::device_alloc(size_t bytes)
+void* DevPlanes::device_alloc(size_t bytes, bool others_hold_planes)
 {
     if (alloc_fails_now()) return nullptr;
-    if (reserve_bytes) {  // (the calling thread has the context's device bound: ctx_bind)
+    // The reserve only makes sense while somebody can give memory back: a caller whose own data fills the device to within
+    // the reserve, with no other plane outstanding, would wait for nothing (and fail after five minutes where the hipMalloc
+    // below succeeds).
+    if (reserve_bytes && others_hold_planes) {  // (the calling thread has the context's device bound: ctx_bind)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
         else if (free_b < bytes + reserve_bytes) return nullptr;
@@ -126,7 +129,7 @@ void* DevPlanes::device_alloc(size_t bytes)
 DevPlanes::Buf DevPlanes::take(size_t bytes)
 {
     for (int attempt = 0; attempt < 2; attempt++) {
-        bool any_idle = false, booked = false;
+        bool any_idle = false, booked = false, others = false;
         {
             std::lock_guard<std::mutex> lk(mu);
             int best = -1;
@@ -135,13 +138,14 @@ DevPlanes::Buf DevPlanes::take(size_t bytes)
             if (best >= 0) { Buf b = idle[best]; idle[best] = idle.back(); idle.pop_back(); return b; }
             any_idle = !idle.empty();
             if (!chunk_limit || allocated + bytes <= chunk_limit) {
+                others = allocated > 0;  // planes in use by any call (this one's earlier chunks included: they drain too) or idle ones
                 allocated += bytes;
                 wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] += bytes;
                 booked = true;
             }
         }
         if (booked) {
-            if (void* q = device_alloc(bytes)) { Buf b; b.p = static_cast<uint8_t*>(q); b.bytes = bytes; return b; }
+            if (void* q = device_alloc(bytes, others)) { Buf b; b.p = static_cast<uint8_t*>(q); b.bytes = bytes; return b; }
             std::lock_guard<std::mutex> lk(mu);
             allocated -= bytes;
             wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] -= bytes;
@@ -170,33 +174,52 @@ constexpr unsigned kLaunchRing = 128;
 LaunchRecord g_launches[kLaunchRing];
 std::atomic<unsigned> g_launch_seq{0};
 
-void fault_log_dump(int)
+// (async-signal-safe: no stdio, no allocation -- digits by hand into a stack buffer, write(2))
+struct Line {
+    char b[768];
+    size_t n = 0;
+    void s(const char* t) { while (*t && n < sizeof b - 1) b[n++] = *t++; }
+    void u(unsigned long long v) { char t[24]; int k = 0; do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k && n < sizeof b - 1) b[n++] = t[--k]; }
+    void x(const void* p) { s("0x"); const unsigned long long v = (unsigned long long)(uintptr_t)p; bool on = false; for (int sh = 60; sh >= 0; sh -= 4) { const unsigned d = (unsigned)(v >> sh) & 15u; if (d || on || !sh) { on = true; if (n < sizeof b - 1) b[n++] = "0123456789abcdef"[d]; } } }
+    void out() { if (n < sizeof b) b[n++] = '\n'; (void)!write(2, b, n); n = 0; }
+};
+struct sigaction g_prev_abort;  // what the host application (or the runtime) had installed before us: it still runs
+
+void fault_log_dump(int sig)
 {
-    char line[640];
+    Line l;
     const unsigned end = g_launch_seq.load();
     const unsigned begin = end > kLaunchRing ? end - kLaunchRing : 0;
-    int len = snprintf(line, sizeof line, "libwaverange_amd: abort -- the last %u plane-kernel launches (oldest first), planes hold %lu bytes of device memory\n",
-                       end - begin, (unsigned long)g_stat[WR_STAT_DEVICE_PLANE_BYTES].load());
-    (void)!write(2, line, (size_t)len);
+    l.s("libwaverange_amd: abort -- the last "); l.u(end - begin); l.s(" plane-kernel launches (oldest first), planes hold ");
+    l.u(g_stat[WR_STAT_DEVICE_PLANE_BYTES].load()); l.s(" bytes of device memory");
+    l.out();
     for (unsigned k = begin; k < end; k++) {
         const LaunchRecord& r = g_launches[k % kLaunchRing];
-        len = snprintf(line, sizeof line, "  #%u t=%.6f ctx=%p dev=%d %s plane=%d x=%p n=%zu partial=%p shift=%u chunks:", k, r.t, r.ctx, r.device, r.what,
-                       r.plane, r.x, r.n, r.partial, r.shift);
+        l.s("  #"); l.u(k); l.s(" t_us="); l.u((unsigned long long)(r.t * 1e6)); l.s(" ctx="); l.x(r.ctx); l.s(" dev="); l.u((unsigned)r.device);
+        l.s(" "); l.s(r.what); l.s(" plane="); l.u((unsigned)r.plane); l.s(" x="); l.x(r.x); l.s(" n="); l.u(r.n); l.s(" partial="); l.x(r.partial);
+        l.s(" shift="); l.u(r.shift); l.s(" chunks:");
         const size_t nch = r.shift >= 63 ? 1 : ((r.n ? r.n - 1 : 0) >> r.shift) + 1;
-        for (size_t i = 0; i < nch && i < (size_t)wrk::kPlaneChunks && len < (int)sizeof line - 24; i++)
-            len += snprintf(line + len, sizeof line - (size_t)len, " %p", r.chunk[i]);
-        if (len < (int)sizeof line - 1) line[len++] = '\n';
-        (void)!write(2, line, (size_t)len);
+        for (size_t i = 0; i < nch && i < (size_t)wrk::kPlaneChunks; i++) { l.s(" "); l.x(r.chunk[i]); }
+        l.out();
     }
-    signal(SIGABRT, SIG_DFL);
+    // then whoever was there before: the application's own handler, or the default action (the core dump)
+    if (g_prev_abort.sa_handler != SIG_DFL && g_prev_abort.sa_handler != SIG_IGN && !(g_prev_abort.sa_flags & SA_SIGINFO)) {
+        sigaction(SIGABRT, &g_prev_abort, nullptr);
+        g_prev_abort.sa_handler(sig);
+        return;
+    }
+    sigaction(SIGABRT, &g_prev_abort, nullptr);  // (an SA_SIGINFO handler wants arguments we do not have: it gets the re-raised signal)
     raise(SIGABRT);
 }
 
 const bool g_fault_log_installed = []() {
     const char* e = getenv("WR_FAULT_LOG");
     if (!(e && atoi(e))) return false;
-    signal(SIGABRT, fault_log_dump);
-    return true;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = fault_log_dump;
+    sigemptyset(&sa.sa_mask);
+    return sigaction(SIGABRT, &sa, &g_prev_abort) == 0;
 }();
 }  // namespace
 
@@ -358,7 +381,6 @@ void planes_configure(DevPlanes& dp)
     size_t c = 1;
     while (c < (mb << 20)) c <<= 1;   // a power of two: the kernels find a byte's chunk by a shift
     dp.chunk_bytes = c;
-    if (const char* e = getenv("WR_PLANE_CHUNKS")) if (!atoi(e)) dp.chunk_bytes = ~(size_t)0 >> 1;  // WR_PLANE_CHUNKS=0: every plane one buffer
     if (const char* e = getenv("WR_PLANE_LIMIT_MB")) { const long v = atol(e); if (v >= 1) dp.chunk_limit = (size_t)v << 20; }
     if (const char* e = getenv("WR_PLANE_RESERVE_MB")) { const long v = atol(e); if (v >= 0) dp.reserve_bytes = (size_t)v << 20; }
 }
@@ -396,24 +418,23 @@ namespace {
 
 // A window callback that must not be served -- its ticket is of an earlier generation of the plane (a coder that outlived
 // its call), it is out of order, it comes after the stream's end, or another callback is inside the same stream -- gets
-// this scratch window instead of the plane's ring and chunk table: the coder it belongs to runs on harmlessly (its bytes
-// are discarded with the call's error), the plane of the call that owns the stream now is not touched.
+// NOTHING: a null window tells the coder to give its stream up at once (wrrc::PlaneWindow; its job ends with (size_t)-1
+// and the call it belongs to fails), and the plane of the call that owns the stream now is not touched.  (Until round 4
+// it got a zeroed scratch window "to run on harmlessly" -- against the GPU's block histograms, in which the count of
+// symbol 0 is normally zero, an encoder on that window had a range of zero and never came back.)
 uint8_t* refused_window(PlaneStream* s, const char* who, const char* why, size_t first, size_t* count)
 {
     static std::mutex mu;
-    static uint8_t* scratch = nullptr;
     g_stat[WR_STAT_HANDOVER_ERRORS]++;
     if (s) s->err = 1;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!scratch) scratch = static_cast<uint8_t*>(calloc(1, kChunkBytes));
         static int reported = 0;
         if (reported++ < 8)
             fprintf(stderr, "libwaverange_amd: plane hand-over violated in %s: %s (first=%zu count=%zu plane stream %p) -- window refused\n", who, why,
                     first, *count, (void*)s);
     }
-    if (*count > kChunkSyms) *count = kChunkSyms;
-    return *count ? scratch : nullptr;
+    return nullptr;
 }
 
 }  // namespace
@@ -635,13 +656,10 @@ int inverse_from_planes(wr_ctx* c, Slot* s, double* d_fld, int nx, int ny, int n
     const size_t n = (size_t)nx * ny * nz;
     const bool fused = wlev == 4 && use_fused(nx, ny, nz, -4);
     if (fused) if (const char* why = wrk::fused_prepare()) return fail(WR_ERR_HIP, why);
-    // (the finest level of the fused inverse can dequantize its detail octants on the way: then only the coarse corner box
-    // is accumulated, inside transform_inv_fused, and the time between ev_a and ev_b is zero)
-    const bool from_planes = fused && wrk::inv_dq_ok(p, nx, ny, nz);
     HIPCHK(hipEventRecord(c->ev_a, c->stream));
-    if (!from_planes) wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
+    wrk::dequant_accum(fused ? s->scratch : d_fld, n, p, c->stream);
     HIPCHK(hipEventRecord(c->ev_b, c->stream));
-    if (fused) wrk::transform_inv_fused(s->scratch, d_fld, s->lowbuf, nx, ny, nz, c->stream, from_planes ? &p : nullptr);
+    if (fused) wrk::transform_inv_fused(s->scratch, d_fld, s->lowbuf, nx, ny, nz, c->stream);
     else wrk::transform(d_fld, s->scratch, nx, ny, nz, -wlev, c->stream);
     HIPCHK(hipEventRecord(c->ev_c, c->stream));
     return WR_OK;
@@ -675,54 +693,28 @@ int read_minmax(wr_ctx* c, const double* d_x, size_t n, bool pending, double* mn
     return WR_OK;
 }
 
-// See DevPool.  The stages of the calls in flight are 8-22 ms long and arrive a few per second, so each one starts on a GPU
-// whose shader clock has fallen back; held back for a moment, two can run back to back.  Measured with 32
-// lanes (profiles/r03/ab_*, ac_*): 150 ms at K = 8 -> the transforms 4.50 / 4.94 ms instead of 4.70 / 5.15 at the same whole-job
-// rate; 400 ms -> 4.46 / 4.90 ms and 9 % off the rate; 100 ms at the driver's K = 20 -> 4.65 / 5.07 ms (0.505 instead of 0.496
-// of peak) and 14.7 instead of 15.8 GB/s: a stage that waits holds its work-space slot and its field its lane, and a
-// transform that is 4 % faster moves nothing else.  Off by default (WR_STAGE_BATCH_MS=0).
-void stage_gather(DevPool* p)
-{
-    static const double window = getenv("WR_STAGE_BATCH_MS") ? atof(getenv("WR_STAGE_BATCH_MS")) * 1e-3 : 0.0;
-    if (window <= 0 || p->active_calls.load() < 8) { std::lock_guard<std::mutex> lk(p->gate_mu); p->gate_waiting++; p->gate_cv.notify_all(); return; }
-    std::unique_lock<std::mutex> lk(p->gate_mu);
-    p->gate_waiting++;
-    p->gate_cv.notify_all();
-    if (now() - p->gate_last_end > 0.005) {  // the GPU has been idle: worth waiting for company
-        const double until = now() + window;
-        while (p->gate_waiting < 2 && now() < until)
-            p->gate_cv.wait_for(lk, std::chrono::duration<double>(until - now()));
-    }
-}
-
-void stage_done(DevPool* p)
-{
-    std::lock_guard<std::mutex> lk(p->gate_mu);
-    if (p->gate_waiting > 0) p->gate_waiting--;
-    p->gate_last_end = now();
-}
-
 // The shader clock of an idle GPU is down, and it takes ~30 ms of load to come all the way up -- longer than a whole
 // kernel stage; the transforms (half VALU issue) run 20-30 % slower at the start of a stage than back to back
 // (tools/clock_burn.py, profiles/r04/c_clock_burner_before_the_transform.txt: forward 4.91 ms cold, 3.77 after 10 ms of fp64
 // arithmetic on every CU, 3.68 after 20 ms, 3.64 warm; waves that merely occupy the CUs asleep do nothing for the clock).
-// The host coder is the long pole of the pipeline and the GPU idles 95 % of the time, so a stage that finds it idle spends
-// WR_CLOCK_WARMUP_MS (default 15, 0: off) of that idle time on a burner kernel in front of its first kernel.  Called with
-// DevPool::cu_mu held: nothing else computes on the device meanwhile.
+// MEASUREMENT HOOK, OFF BY DEFAULT (WR_CLOCK_WARMUP_MS=k, k <= 200): a stage that finds the GPU idle puts k ms of fp64 load on
+// every CU in front of its first kernel.  It shows what the transform kernels do at full clock inside the pipeline (4.69 /
+// 5.09 -> 4.14 / 4.64 ms at k = 15) and it buys NOTHING: the whole-job rate is set by the host coder and did not move
+// (14.56 against 14.54 GB/s, profiles/r04/b_ and d_bench_k8_*), while the burner was 55-75 % of all GPU kernel time and
+// stretched a 17 ms kernel stage to 57 ms (round 4 shipped it on at 40 ms; the review was right to call that buying a
+// fraction with a busy-loop).  Called with DevPool::cu_mu held: nothing else computes on the device meanwhile.
 void clock_warmup(wr_ctx* c, size_t n)
 {
-    static const double ms = []() { const char* e = getenv("WR_CLOCK_WARMUP_MS"); const double v = e ? atof(e) : 40.0; return v < 0 ? 0.0 : (v > 200 ? 200.0 : v); }();
+    static const double ms = []() { const char* e = getenv("WR_CLOCK_WARMUP_MS"); const double v = e ? atof(e) : 0.0; return v < 0 ? 0.0 : (v > 200 ? 200.0 : v); }();
     if (ms <= 0) return;
     DevPool* p = c->pool;
-    // Only where it is free: eight or more calls in flight on this device (a pipeline whose GPU idles between kernel stages:
-    // the burner takes nothing from anybody) and fields of 2 GiB or more (their transforms are milliseconds long; the tools on
-    // 512^3 fields would only see 40 ms more latency per field).  A lone
-    // caller would pay tens of milliseconds of latency to save one.  (40 ms: profiles/r04/c_clock_burner_before_the_transform.txt,
-    // a forward transform after half a second of idle 4.91 ms, behind 10 / 20 / 40 / 80 ms of load 3.77 / 3.68 / 3.64 / 3.65.)
-    if (p->active_calls.load() < 8 || n < ((size_t)1 << 28)) return;
+    (void)n;
+    // (profiles/r04/c_clock_burner_before_the_transform.txt: a forward transform after half a second of idle 4.91 ms, behind
+    // 10 / 20 / 40 / 80 ms of load 3.77 / 3.68 / 3.64 / 3.65)
     if (now() - p->last_stage_end.load() < 0.004) return;  // a stage has just ended: the clock is up
     wrk::burn(ms, 0, 1024, c->d_partial, c->stream);
     (void)hipGetLastError();
+    g_stat[WR_STAT_CLOCK_WARMUP_MS] += (unsigned long)ms;
 }
 
 int check_dims(int nx, int ny, int nz, const void* dev_ptr)
@@ -761,7 +753,7 @@ unsigned long wr_stat(int what)
     if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
     if (what == WR_STAT_POOL_STREAMS_MOVED) return wrrc::pool_streams_moved();
     if (what == WR_STAT_POOL_QUEUE_MS) return (unsigned long)(wrrc::pool_queue_seconds() * 1e3);
-    return (what >= 0 && what < 8) ? g_stat[what].load() : 0;
+    return (what >= 0 && what < 12) ? g_stat[what].load() : 0;
 }
 void wr_set_coder_pool(int nthreads, int decoder_streams)
 {

@@ -82,7 +82,9 @@ struct Enc {
     // rangecod.c:182-207
     inline void renorm()
     {
-        while (range <= kBottom) {
+        // (range - 1 < Bottom: as range <= Bottom, except that a range of ZERO -- which only a block model that does not
+        // belong to the symbols can produce, see block_failed -- ends the loop instead of feeding it for ever)
+        while (range - 1u < kBottom) {
             if (low & kTop) carry();
             out[pos++] = (uint8_t)(low >> kShift);
             range <<= 8;
@@ -171,7 +173,7 @@ inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry
         pos += sh;
         low = sh ? (low << 8) & (kTop - 1) : low;
         range = sh ? range << 8 : range;
-        while (__builtin_expect(range <= kBottom, 0)) {
+        while (__builtin_expect(range - 1u < kBottom, 0)) {  // (range 0: see Enc::renorm)
             if (low & kTop) {
                 size_t p = pos - 1;
                 while (++out[p] == 0) p--;
@@ -183,7 +185,6 @@ inline void encode_symbols(Enc& e, const uint8_t* s, uint32_t bs, const SymEntry
         const uint32_t r = range / tot;
         const uint32_t t = r * tab[c].lt;
         low += t;
-        // lt + sy < tot holds for every symbol except the largest one present (rangecod.c:227)
         // lt + sy < tot holds for every symbol except the largest one present (rangecod.c:227)
         range = TOPSEL ? select_u32(c ^ top_sym, r * tab[c].sy, range - t) : ((c != top_sym) ? r * tab[c].sy : range - t);
     }
@@ -221,6 +222,10 @@ size_t encode_bound(size_t n)
 //   encode_freq(1, 1, 2) / (1, 0, 2):     range after >= range / 2 * (1 - 2 / 2^23)
 // (the last symbol present gets the rounding remainder on top: rangecod.c:227).  Summed: the entropy of every block under
 // its own histogram, 513 header bytes per block, and at most 0.0104 bit per symbol of rounding loss.
+// The same sum taken over the first b blocks bounds the stream's position after block b, so a coder that is given the bound
+// (PlaneJob::dst_limit) can tell after every block whether the histograms were the plane's: a position beyond it is proof
+// that they were not, found at most one block late -- and a block cannot put out more than 2 bytes per symbol plus its
+// header (a coding step with a count of 1 or more costs at most log2(60000) + 0.01 bits), which is kFailedBlockSlack.
 size_t encode_bound_hist(const uint16_t* hists, size_t n)
 {
     static const std::vector<double> lg = []() {
@@ -285,7 +290,7 @@ inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const
             // this loop, and on a plane of ~1 bit per symbol "a byte leaves now" is badly predicted
             low[k] = select_u32(sh, (low[k] << 8) & (kTop - 1), low[k]);
             range[k] = select_u32(sh, range[k] << 8, range[k]);
-            while (__builtin_expect(range[k] <= kBottom, 0)) {
+            while (__builtin_expect(range[k] - 1u < kBottom, 0)) {  // (range 0: see Enc::renorm)
                 if (low[k] & kTop) {
                     size_t p = pos[k] - 1;
                     while (++out[k][p] == 0) p--;
@@ -304,13 +309,23 @@ inline void encode_symbols_multi(Enc* const* es, const uint8_t* const* ss, const
     for (int k = 0; k < NS; k++) { es[k]->low = low[k]; es[k]->range = range[k]; es[k]->pos = pos[k]; }
 }
 
-// block header of wrappers.cpp:85-113: "a block follows", then the 256 counts
-inline void encode_block_header(Enc& e, const uint8_t* s, uint32_t bs, const uint16_t* hist, SymEntry* tab, uint32_t* top_sym)
+// block header of wrappers.cpp:85-113: "a block follows", then the 256 counts.
+// false: the histogram that came with the plane (the GPU counts it next to the quantizer) does not add up to the block --
+// it is not this block's, the stream is given up (nothing has been written for the block).  A histogram that adds up and is
+// still not the symbols' shows while the block is coded: a symbol with a count of zero leaves the coder with a range of
+// zero (Enc::renorm ends on it, the 16-lane loop retires the lane), which the callers test for after every block
+// (block_failed).  Either way the stream ends at once and its job reports (size_t)-1; at most one byte per symbol of the
+// block has been written by then (kFailedBlockSlack: what a buffer sized by encode_bound_hist needs on top).
+inline bool encode_block_header(Enc& e, const uint8_t* s, uint32_t bs, const uint16_t* hist, SymEntry* tab, uint32_t* top_sym)
 {
-    e.freq(1, 1, 2);
     uint32_t h[256];
-    if (hist) { for (int b = 0; b < 256; b++) h[b] = hist[b]; }
-    else histogram(s, bs, h);
+    if (hist) {
+        uint32_t sum = 0;
+        for (int b = 0; b < 256; b++) { h[b] = hist[b]; sum += h[b]; }
+        if (sum != bs) return false;
+    } else
+        histogram(s, bs, h);
+    e.freq(1, 1, 2);
     uint32_t cum = 0, top = 0;
     for (int b = 0; b < 256; b++) {
         e.shift(1, h[b], 16);  // encode_short(count), rangecod.h:155
@@ -319,7 +334,10 @@ inline void encode_block_header(Enc& e, const uint8_t* s, uint32_t bs, const uin
         if (h[b]) top = (uint32_t)b;
     }
     *top_sym = top;
+    return true;
 }
+// after a block: the coder's state says that the block model was not the symbols' (see encode_block_header)
+inline bool block_failed(const Enc& e) { return e.range == 0; }
 
 }  // namespace
 
@@ -333,18 +351,22 @@ struct SymCursor {
     uint8_t* base = nullptr;
     size_t first = 0, count = 0;  // extent of what `base` points at
     const PlaneWindow* io = nullptr;
+    bool refused = false;         // the plane's owner turned a window request down (PlaneWindow): the stream is to end at once
     void set(const uint8_t* whole, size_t n, const PlaneWindow* w)
     {
-        io = w; first = 0;
+        io = w; first = 0; refused = false;
         if (w) { base = nullptr; count = 0; } else { base = const_cast<uint8_t*>(whole); count = n; }
     }
-    // symbol `pos` of a plane of n symbols; moves the window on when pos has run out of it
+    // symbol `pos` of a plane of n symbols; moves the window on when pos has run out of it.  nullptr (and `refused`): the
+    // request was turned down -- the caller gives the stream up without touching a symbol
     uint8_t* at(size_t pos, size_t n)
     {
+        if (refused) return nullptr;
         if (io && pos >= first + count && pos < n) {
             size_t c = n - pos;
-            base = io->window(io->user, pos, &c);
-            first = pos; count = c;
+            uint8_t* const w = io->window(io->user, pos, &c);
+            if (!w || !c) { refused = true; base = nullptr; first = pos; count = 0; return nullptr; }
+            base = w; first = pos; count = c;
         }
         return base + (pos - first);
     }
@@ -364,17 +386,19 @@ public:
     struct Stream {
         SymCursor sym; size_t n, done, blk; const uint16_t* hist;
         void* tag;
+        bool failed = false;  // a refused window or a block model that is not the symbols': ends with (size_t)-1
+        size_t limit = 0;     // what a stream coded with this plane's own histograms never exceeds (0: not known, not checked)
     };
     int count() const { return count_; }
     bool full() const { return count_ == kMaxEncStreams; }
-    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag, const PlaneWindow* io = nullptr)
+    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag, const PlaneWindow* io = nullptr, size_t limit = 0)
     {
         const int k = count_++;
         es_[k] = new (store_[k]) Enc(out);
-        st_[k] = Stream{SymCursor(), n, 0, 0, hist, tag};
+        st_[k] = Stream{SymCursor(), n, 0, 0, hist, tag, false, hist ? limit : 0};
         st_[k].sym.set(sym, n, io);
     }
-    // one block of every stream; on_end(tag, stream length) for the streams that ended with it
+    // one block of every stream; on_end(tag, stream length or (size_t)-1) for the streams that ended with it
     template <class OnEnd>
     void step(OnEnd on_end) { step_streams(count_, es_, store_, st_, tabs_, tops_, on_end); }
     // the same on the slots of another holder of at most kMaxEncStreams streams (a 16-lane session that is down to a few)
@@ -390,7 +414,10 @@ public:
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
             ss[k] = s.sym.at(s.done, s.n);
-            encode_block_header(*es[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs[k], &tops[k]);
+            if ((!ss[k] && bs[k]) || !encode_block_header(*es[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs[k], &tops[k])) {
+                s.failed = true; bs[k] = 0; all_full = false;
+                continue;
+            }
             all_full = all_full && bs[k] == kBlock;
             topsel = topsel || (uint64_t)tabs[k][tops[k]].sy * 50 > bs[k];
         }
@@ -402,16 +429,21 @@ public:
             }
         } else {
             for (int k = 0; k < count; k++) {
+                if (st[k].failed) continue;
                 if (bs[k] == kBlock) encode_symbols<kBlock, true>(*es[k], ss[k], kBlock, tabs[k], tops[k]);
                 else if (bs[k]) encode_symbols<0, true>(*es[k], ss[k], bs[k], tabs[k], tops[k]);
             }
         }
         for (int k = 0; k < count;) {
+            const bool failed = st[k].failed || block_failed(*es[k]) || (st[k].limit && es[k]->pos > st[k].limit);
             st[k].done += bs[k];
             st[k].blk++;
-            if (bs[k] == kBlock) { k++; continue; }
-            es[k]->freq(1, 0, 2);  // "no more blocks"
-            on_end(st[k].tag, es[k]->finish());
+            if (!failed && bs[k] == kBlock) { k++; continue; }
+            if (failed) on_end(st[k].tag, (size_t)-1);
+            else {
+                es[k]->freq(1, 0, 2);  // "no more blocks"
+                on_end(st[k].tag, es[k]->finish());
+            }
             // the last slot moves into the hole (its block size with it: it has not been looked at yet)
             const int last = --count;
             if (k != last) {
@@ -431,14 +463,12 @@ private:
     uint32_t tops_[kMaxEncStreams];
 };
 
-// A 16-lane session that holds no more streams than a scalar loop takes runs them through that loop (WR_VEC_SMALL_SCALAR=0:
-// never): per stream and per thread it is the faster one there (EPYC 9575F, dominant-symbol planes, Msym/s per stream:
-// encoder 1 / 2 / 3 streams scalar ~300 / ~250 / 190 against ~110 in the vector loop at <= 4 lanes; decoder 304 / 214 / 142
-// against ~110).  Sessions get that small when a run fills or drains, with a lone caller, and after idle workers have taken
-// over half of a session's streams.
-const bool kSmallScalar = !(getenv("WR_VEC_SMALL_SCALAR") && !atoi(getenv("WR_VEC_SMALL_SCALAR")));
-// two 16-lane groups per vector session, their symbol loops interleaved (DualVecDecGroup)
-const bool kVecDual = getenv("WR_VEC_DUAL") && atoi(getenv("WR_VEC_DUAL"));
+// A 16-lane session that holds no more streams than a scalar loop takes runs them through that loop: per stream and per
+// thread it is the faster one there (EPYC 9575F, dominant-symbol planes, Msym/s per stream: encoder 1 / 2 / 3 streams scalar
+// ~300 / ~250 / 190 against ~110 in the vector loop at <= 4 lanes; decoder 304 / 214 / 142 against ~110).  Sessions get
+// that small when a run fills or drains, with a lone caller, and after idle workers have taken over half of a session's
+// streams.  (Two 16-lane groups per session with interleaved steps, 2.3 Gsym/s per thread at 72 Msym/s per stream, lost in
+// the pipeline and is gone: profiles/r03/NOTES.md.)
 
 }  // namespace
 
@@ -460,11 +490,11 @@ public:
     VecEncGroup() { memset(tabs_, 0, sizeof tabs_); }
     int count() const { return count_; }
     bool full() const { return count_ == kCap; }
-    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag, const PlaneWindow* io = nullptr)
+    void add(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hist, void* tag, const PlaneWindow* io = nullptr, size_t limit = 0)
     {
         const int k = count_++;
         es_[k] = new (store_[k]) Enc(out);
-        st_[k] = EncGroup::Stream{SymCursor(), n, 0, 0, hist, tag};
+        st_[k] = EncGroup::Stream{SymCursor(), n, 0, 0, hist, tag, false, hist ? limit : 0};
         st_[k].sym.set(sym, n, io);
     }
     // hand the last stream over (call between steps) / adopt one
@@ -484,10 +514,11 @@ public:
     template <class OnEnd>
     void step(OnEnd on_end)
     {
-        if (kSmallScalar && count_ <= kMaxEncStreams) { EncGroup::step_streams(count_, es_, store_, st_, tabs_, tops_, on_end); return; }
+        if (count_ <= kMaxEncStreams) { EncGroup::step_streams(count_, es_, store_, st_, tabs_, tops_, on_end); return; }
         uint32_t bs[kCap];
         VecEncBlock vb;
         vb.active = 0;
+        vb.failed = 0;
         vb.gather = 0;
         vb.tab = &tabs_[0][0].lt;
         vb.packed = &packed_[0][0];
@@ -497,7 +528,10 @@ public:
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
             ss[k] = s.sym.at(s.done, s.n);
-            encode_block_header(*es_[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]);
+            if ((!ss[k] && bs[k]) || !encode_block_header(*es_[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k])) {
+                s.failed = true; bs[k] = 0;
+                continue;
+            }
             if (bs[k] != kBlock) {  // the final, partial block of a stream: scalar
                 if (bs[k]) encode_symbols<0, true>(*es_[k], ss[k], bs[k], tabs_[k], tops_[k]);
                 continue;
@@ -531,17 +565,24 @@ public:
             if (vb.gather)
                 for (int k = 0; k < kCap; k++)
                     if (vb.active >> k & 1)
-                        for (int b = 0; b < 256; b++) packed_[k][b] = tabs_[k][b].lt | (((uint32_t)b == tops_[k] ? 0u : tabs_[k][b].sy) << 16);
+                        for (int b = 0; b < 256; b++) packed_[k][b] = tabs_[k][b].lt | (((uint32_t)b == tops_[k] ? kVecTopMark : tabs_[k][b].sy) << 16);
             vec_encode_block(&vb);
-            for (int k = 0; k < count_; k++)
-                if (vb.active >> k & 1) { es_[k]->low = vb.low[k]; es_[k]->range = vb.range[k]; es_[k]->pos = vb.pos[k]; }
+            for (int k = 0; k < count_; k++) {
+                if (!(vb.active >> k & 1)) continue;
+                if (vb.failed >> k & 1) { st_[k].failed = true; continue; }  // (the lane was retired inside the block)
+                es_[k]->low = vb.low[k]; es_[k]->range = vb.range[k]; es_[k]->pos = vb.pos[k];
+            }
         }
         for (int k = 0; k < count_;) {
+            const bool failed = st_[k].failed || block_failed(*es_[k]) || (st_[k].limit && es_[k]->pos > st_[k].limit);
             st_[k].done += bs[k];
             st_[k].blk++;
-            if (bs[k] == kBlock) { k++; continue; }
-            es_[k]->freq(1, 0, 2);  // "no more blocks"
-            on_end(st_[k].tag, es_[k]->finish());
+            if (!failed && bs[k] == kBlock) { k++; continue; }
+            if (failed) on_end(st_[k].tag, (size_t)-1);
+            else {
+                es_[k]->freq(1, 0, 2);  // "no more blocks"
+                on_end(st_[k].tag, es_[k]->finish());
+            }
             const int last = --count_;
             if (k != last) {
                 es_[k] = new (store_[k]) Enc(*es_[last]);
@@ -557,7 +598,7 @@ private:
     alignas(Enc) unsigned char store_[kCap][sizeof(Enc)];
     EncGroup::Stream st_[kCap];
     SymEntry tabs_[kCap][256];  // contiguous: the vector loop gathers {lt, sy} at (lane * 256 + symbol)
-    alignas(64) uint32_t packed_[kCap][256];  // the same as lt | sy << 16 (sy = 0: the largest symbol present) for the per-lane look-ups
+    alignas(64) uint32_t packed_[kCap][256];  // the same as lt | sy << 16 (sy = kVecTopMark: the largest symbol present) for the per-lane look-ups
     uint32_t tops_[kCap];
 };
 
@@ -582,14 +623,14 @@ bool encode_planes_vec(int count, const uint8_t* const* sym, const size_t* n, ui
 }
 
 void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens,
-                   const PlaneWindow* const* io)
+                   const PlaneWindow* const* io, const size_t* limits)
 {
     // up to kMaxEncStreams planes at a time in one symbol loop; further planes join as earlier ones end
     EncGroup g;
     int next = 0;
     while (next < count || g.count()) {
         while (next < count && !g.full()) {
-            g.add(sym[next], n, out[next], (hists && hists[next]) ? hists[next] : nullptr, lens + next, io ? io[next] : nullptr);
+            g.add(sym[next], n, out[next], (hists && hists[next]) ? hists[next] : nullptr, lens + next, io ? io[next] : nullptr, limits ? limits[next] : 0);
             next++;
         }
         g.step([](void* tag, size_t len) { *static_cast<size_t*>(tag) = len; });
@@ -735,14 +776,10 @@ struct BlockModel {
     uint8_t lookup[kBlock + kPad];
 };
 constexpr uint16_t kMixed = 0x100;
-#ifndef WR_RC_MIXED_PCT
-#define WR_RC_MIXED_PCT 2
-#endif
 #ifndef WR_RC_MPS_PCT
 #define WR_RC_MPS_PCT 90
 #endif
-
-const uint32_t kMixedPct = getenv("WR_RC_MIXED_PCT") ? (uint32_t)atoi(getenv("WR_RC_MIXED_PCT")) : WR_RC_MIXED_PCT;
+constexpr uint32_t kMixedPct = 2;  // (1 .. 8 measured on EPYC 9575F: profiles/r04/t_rc_noise_bucket_threshold_epyc9575f.txt)
 
 // the look-up side of a block model (60 KB + buckets): what the division path needs
 void finish_model_tables(BlockModel& m)
@@ -1073,12 +1110,11 @@ void decode_symbols_noise4_asm(Dec* const* ds, uint8_t* const* dst, const BlockM
 #undef WR_NOISE_STREAM
 #undef WR_NOISE_TAILS
 
-const bool kNoiseAsm = !(getenv("WR_RC_NOISE_ASM") && !atoi(getenv("WR_RC_NOISE_ASM")));
+constexpr bool kNoiseAsm = true;
 #else
-const bool kNoiseAsm = false;
+constexpr bool kNoiseAsm = false;
 inline void decode_symbols_noise4_asm(Dec* const*, uint8_t* const*, const BlockModel* const*) {}
 #endif
-const bool kNoiseLoop = !(getenv("WR_RC_NOISE_LOOP") && !atoi(getenv("WR_RC_NOISE_LOOP")));
 
 using MultiFn = void (*)(Dec* const*, uint8_t* const*, const BlockModel* const*);
 template <int NS, unsigned... M>
@@ -1091,7 +1127,7 @@ inline void decode_block_multi(int count, Dec* const* ds, uint8_t* const* dst, c
 {
     unsigned mask = 0, buckets = 0;
     for (int k = 0; k < count; k++) { mask |= (ms[k]->mps_on ? 1u : 0u) << k; buckets |= ms[k]->use_buckets ? 1u : 0u; }
-    if (!mask && !buckets && kNoiseLoop) {
+    if (!mask && !buckets) {
         switch (count) {
         case 1: decode_symbols_noise<1>(ds, dst, ms); break;
         case 2: decode_symbols_noise<2>(ds, dst, ms); break;
@@ -1135,6 +1171,7 @@ inline void decode_block_checked(Dec& d, const BlockModel& m, SymCursor& cur, ui
     size_t done = 0;
     while (done < m.bs && at + done < n) {
         uint8_t* const w = cur.at(at + done, n);  // moves the window on when `at + done` has run out of it
+        if (!w) break;  // refused: the caller sees cur.refused
         size_t r = cur.room(at + done);
         if (r > m.bs - done) r = m.bs - done;
         if (!r) break;
@@ -1206,6 +1243,7 @@ public:
             if (ended) { retire(k, on_end); continue; }
             const size_t at = produced_[k] < n_[k] ? produced_[k] : n_[k];
             dst_[k] = cur_[k].at(at, n_[k]);
+            if (cur_[k].refused) { failed_[k] = true; retire(k, on_end); continue; }  // the plane's owner turned the window down
             if (d.pos + kMargin > d.len && tails_[k].empty() && d.pos >= 1 && d.pos <= d.len) {
                 // near the end of the stream: continue on a zero-padded copy of the rest (reading past
                 // the end yields zeros, Dec::get), so that the unchecked loop stays usable
@@ -1226,7 +1264,7 @@ public:
             const BlockModel& m = *ms_[k];
             decode_block_checked(*ds_[k], m, cur_[k], dst_[k], produced_[k] < n_[k] ? produced_[k] : n_[k], n_[k], bounce_);
             produced_[k] += m.bs;
-            if (ds_[k]->pos > ds_[k]->len + 8) { failed_[k] = true; retire(k, on_end); continue; }  // ran far past the end: corrupt stream
+            if (ds_[k]->pos > ds_[k]->len + 8 || cur_[k].refused) { failed_[k] = true; retire(k, on_end); continue; }  // ran far past the end: corrupt stream
             k++;
         }
     }
@@ -1286,18 +1324,9 @@ uint32_t vec_other_symbol(const void* model, uint32_t* low, uint32_t* range, uin
 class VecDecGroup {
 public:
     static constexpr int kCap = kVecLanes;
-    // any: the loop for planes of any statistics (vec_decode_block_any: division + table look-ups per lane) instead of
-    // the candidate-compare loop for dominant-symbol planes
-    explicit VecDecGroup(bool any = false) : any_(any), models_((size_t)kCap)
+    VecDecGroup() : models_((size_t)kCap)
     {
         for (int k = 0; k < kCap; k++) ms_[k] = &models_[k];
-        if (any_) {
-            arena_.reset(static_cast<uint8_t*>(aligned_alloc(64, (size_t)kCap * kAnyStride)));
-            packed_.reset(static_cast<uint32_t*>(aligned_alloc(64, (size_t)kCap * 256 * sizeof(uint32_t))));
-            if (!arena_ || !packed_) throw std::bad_alloc();
-            memset(arena_.get(), 0, (size_t)kCap * kAnyStride);
-            memset(packed_.get(), 0, (size_t)kCap * 256 * sizeof(uint32_t));
-        }
     }
     int count() const { return count_; }
     bool full() const { return count_ == kCap; }
@@ -1331,10 +1360,9 @@ public:
         if (vb.active) vec_decode_block(&vb, vec_other_symbol);
         finish(vb, on_end);
     }
-    // A step in two halves, so that two groups can share one symbol loop (DualVecDecGroup).  prepare: block headers of
-    // all streams (streams that end leave), the lanes of the vector loop in vb (vb.active may be 0); false: nothing left
-    // to do in this step (no streams, or they went through another loop already).  finish: lane state back to the
-    // streams, the other streams' blocks through the scalar loop.
+    // A step in two halves.  prepare: block headers of all streams (streams that end leave), the lanes of the vector loop in
+    // vb (vb.active may be 0); false: nothing left to do in this step (no streams, or they went through another loop
+    // already).  finish: lane state back to the streams, the other streams' blocks through the scalar loop.
     template <class OnEnd>
     bool prepare(OnEnd on_end, VecBlock& vb)
     {
@@ -1360,33 +1388,31 @@ public:
                 if (bs > kBlock) { failed_[k] = true; ended = true; }
                 else {
                     m.top = top_sym; m.bs = bs;
-                    if (any_) m.tables_ready = false; else finish_model_stats(m);
+                    finish_model_stats(m);
                 }
             }
             if (ended) { retire(k, on_end); continue; }
             const size_t at = produced_[k] < n_[k] ? produced_[k] : n_[k];
             dst_[k] = cur_[k].at(at, n_[k]);
+            if (cur_[k].refused) { failed_[k] = true; retire(k, on_end); continue; }
             if (d.pos + kMargin > d.len && tails_[k].empty() && d.pos >= 1 && d.pos <= d.len) {
                 tails_[k].assign(d.len - (d.pos - 1) + kMargin, 0);
                 memcpy(tails_[k].data(), d.in + (d.pos - 1), d.len - (d.pos - 1));
                 d.in = tails_[k].data(); d.len = tails_[k].size(); d.pos = 1;
             }
             const bool fast = m.bs == kBlock && cur_[k].room(at) >= kBlock && d.pos + kMargin <= d.len;
-            vec[k] = fast && (any_ || m.cand_ok);
+            vec[k] = fast && m.cand_ok;
             all_fast = all_fast && fast;
             k++;
         }
         if (!count_) return false;
-        if (kSmallScalar && all_fast && count_ < kMaxDecStreams) {  // down to a few streams: the scalar loop of up to three (kSmallScalar)
-            for (int k = 0; k < count_; k++) {
-                if (any_) finish_model_stats(*ms_[k]);
+        if (all_fast && count_ < kMaxDecStreams) {  // down to a few streams: the scalar loop of up to three
+            for (int k = 0; k < count_; k++)
                 if (!ms_[k]->tables_ready) finish_model_tables(*ms_[k]);
-            }
             decode_block_multi(count_, ds_, dst_, ms_);
             for (int k = 0; k < count_; k++) produced_[k] += kBlock;
             return false;
         }
-        if (any_) { step_any(vec); finish_slow(vec, on_end); return false; }
         for (int k = 0; k < count_; k++) {
             if (!vec[k]) continue;
             const Dec& d = *ds_[k];
@@ -1440,7 +1466,7 @@ private:
             if (!m.tables_ready) finish_model_tables(m);
             decode_block_checked(*ds_[k], m, cur_[k], dst_[k], produced_[k] < n_[k] ? produced_[k] : n_[k], n_[k], bounce_);
             produced_[k] += m.bs;
-            if (ds_[k]->pos > ds_[k]->len + 8) {
+            if (ds_[k]->pos > ds_[k]->len + 8 || cur_[k].refused) {
                 failed_[k] = true;
                 const int last = count_ - 1;
                 retire(k, on_end);
@@ -1450,40 +1476,6 @@ private:
             k++;
         }
     }
-    // the full blocks of this step through vec_decode_block_any: per lane the symbol-of-cumulative-frequency table (60 KB,
-    // rebuilt per block like the scalar loop's) and the packed {lt, sy} entries
-    void step_any(const bool* vec)
-    {
-        VecAnyBlock vb;
-        vb.active = 0;
-        vb.lookup = arena_.get();
-        vb.packed = packed_.get();
-        for (int k = 0; k < count_; k++) {
-            if (!vec[k]) continue;
-            const Dec& d = *ds_[k];
-            const BlockModel& m = *ms_[k];
-            vb.active |= 1u << k;
-            vb.low[k] = d.low; vb.range[k] = d.range; vb.ptr[k] = d.in + d.pos; vb.dst[k] = dst_[k];
-            uint8_t* const lk = arena_.get() + (size_t)k * kAnyStride;
-            uint32_t* const pk = packed_.get() + k * 256;
-            for (int b = 0; b < 256; b++) {
-                if (m.tab[b].sy) memset(lk + m.tab[b].lt, b, m.tab[b].sy);
-                pk[b] = m.tab[b].lt | (((uint32_t)b == m.top ? 0u : m.tab[b].sy) << 16);
-            }
-            memset(lk + m.bs, (int)m.top, kAnyStride - m.bs);  // low / help can exceed tot - 1 by a few hundred (decode_symbols)
-        }
-        if (!vb.active) return;
-        for (int k = 0; k < kCap; k++)
-            if (!(vb.active >> k & 1)) { vb.low[k] = 0; vb.range[k] = 0; vb.ptr[k] = nullptr; vb.dst[k] = nullptr; }
-        vec_decode_block_any(&vb);
-        for (int k = 0; k < count_; k++) {
-            if (!vec[k]) continue;
-            Dec& d = *ds_[k];
-            d.low = vb.low[k]; d.range = vb.range[k]; d.pos = (size_t)(vb.ptr[k] - d.in); d.held = vb.ptr[k][-1];
-            produced_[k] += kBlock;
-        }
-    }
-
     template <class OnEnd>
     void retire(int k, OnEnd on_end)
     {
@@ -1500,11 +1492,7 @@ private:
         tails_[last].clear();
     }
 
-    struct FreeDeleter { void operator()(void* p) const { free(p); } };
-    const bool any_;
     bool vec_[kCap];  // this step: the stream's block goes through the vector loop
-    std::unique_ptr<uint8_t, FreeDeleter> arena_;    // any_: [kCap][kAnyStride] symbol of every cumulative frequency
-    std::unique_ptr<uint32_t, FreeDeleter> packed_;  // any_: [kCap][256] lt | sy << 16
     int count_ = 0;
     std::vector<BlockModel> models_;
     BlockModel* ms_[kCap];
@@ -1519,50 +1507,12 @@ private:
     std::vector<uint8_t> bounce_;  // decode_block_checked
 };
 
-// Two 16-lane groups of dominant-symbol planes whose symbol loops run interleaved on one thread (vec_decode_block2): the
-// second group's step fills the issue slots the first one's dependency chain leaves empty.  Streams go to the first
-// group while it has room, so that up to 16 streams run as one group.
-class DualVecDecGroup {
-public:
-    int count() const { return a_.count() + b_.count(); }
-    bool full() const { return a_.full() && b_.full(); }
-    void add(const uint8_t* in, size_t len, uint8_t* sym, size_t n, void* tag, const PlaneWindow* io = nullptr)
-    {
-        last_ = a_.full() ? &b_ : &a_;
-        last_->add(in, len, sym, n, tag, io);
-    }
-    DecStream give() { return (b_.count() ? b_ : a_).give(); }
-    void take(DecStream&& m)
-    {
-        last_ = a_.full() ? &b_ : &a_;
-        last_->take(std::move(m));
-    }
-    void set_tag_of_last(void* t) { last_->set_tag_of_last(t); }
-    template <class OnEnd>
-    void step(OnEnd on_end)
-    {
-        VecBlock va, vb;
-        const bool ra = a_.prepare(on_end, va), rb = b_.prepare(on_end, vb);
-        if (ra && rb && va.active && vb.active) vec_decode_block2(&va, &vb, vec_other_symbol);
-        else {
-            if (ra && va.active) vec_decode_block(&va, vec_other_symbol);
-            if (rb && vb.active) vec_decode_block(&vb, vec_other_symbol);
-        }
-        if (ra) a_.finish(va, on_end);
-        if (rb) b_.finish(vb, on_end);
-    }
-
-private:
-    VecDecGroup a_, b_;
-    VecDecGroup* last_ = &a_;
-};
-
 }  // namespace
 
 // `count` streams of dominant-symbol planes (any lengths) on the calling thread through the 16-lane loop: test
 // and measurement hook; the coder pool is the product path.  False if the CPU lacks AVX-512.
 bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced,
-                       const PlaneWindow* const* io, bool any)
+                       const PlaneWindow* const* io)
 {
     if (!vec_available()) return false;
     auto run = [&](auto& g) {
@@ -1576,8 +1526,8 @@ bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, u
             g.step([](void* tag, size_t got) { *static_cast<size_t*>(tag) = got; });
         }
     };
-    if (kVecDual && !any) { std::unique_ptr<DualVecDecGroup> g(new DualVecDecGroup); run(*g); }
-    else { std::unique_ptr<VecDecGroup> g(new VecDecGroup(any)); run(*g); }
+    std::unique_ptr<VecDecGroup> g(new VecDecGroup);
+    run(*g);
     return true;
 }
 
@@ -1649,12 +1599,10 @@ public:
             // planes below 2 bits per symbol are the dominant-symbol kind: they go to the 16-lane vector loop
             const bool vec = jobs[i].kind == PlaneJob::kDecode && vec_ok_ && jobs[i].n >= 4 * (size_t)kBlock &&
                              8 * jobs[i].src_len < 2 * jobs[i].n;
-            // encoder (opt-in): every plane takes the vector loop (candidate compares while all lanes of a session hold
+            // encoder: every plane takes the vector loop (candidate compares while all lanes of a session hold
             // dominant-symbol blocks, gathers from the lanes' tables otherwise)
             const bool venc = jobs[i].kind == PlaneJob::kEncode && vec_ok_ && vec_enc_ && jobs[i].n >= 4 * (size_t)kBlock;
-            // the other decoder planes (noise: ~7 bits per symbol): the 16-lane loop for planes of any statistics
-            const bool vany = jobs[i].kind == PlaneJob::kDecode && !vec && vec_ok_ && vec_any_ && jobs[i].n >= 4 * (size_t)kBlock;
-            (vec ? vec_q_ : venc ? venc_q_ : vany ? vany_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
+            (vec ? vec_q_ : venc ? venc_q_ : jobs[i].kind == PlaneJob::kDecode ? dec_q_ : enc_q_).push_back(&jobs[i]);
         }
         { std::lock_guard<std::mutex> bl(batch->mu); batch->remaining += count; }
         if (count > 1) cv_.notify_all(); else cv_.notify_one();
@@ -1663,24 +1611,20 @@ public:
     ~Pool() { resize(0, 0); }
 
 private:
-    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2, kVecEnc = 3, kVecAny = 4 };
+    enum Want { kAny = -1, kEnc = 0, kDec = 1, kVec = 2, kVecEnc = 3 };
     // kAny: vector-decode jobs first (one worker absorbs up to 16 of them), then decode, then encode
     PlaneJob* pop(bool block, int want, int* got = nullptr)
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
             // at most vec_sessions_max() / venc_sessions_max() workers run a vector session of either kind at a time
-            // (WR_VEC_SESSIONS, WR_VEC_ENC_SESSIONS; default 5/16 and 3/8 of the workers): a session is worth its core
+            // (5/16 and 3/8 of the workers): a session is worth its core
             // with many lanes filled, but every stream in it advances the slower the fuller it is, so their number is
             // what balances CPU time against the time a field waits for its planes (profiles/r02/NOTES.md); what is
             // queued beyond that joins a running session at its next block boundary
             if (want == kVec && !vec_q_.empty()) { PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); return j; }
             if (want == kAny && !vec_q_.empty() && vec_sessions_ < vec_sessions_max()) {
                 PlaneJob* j = vec_q_.front(); vec_q_.pop_front(); vec_sessions_++; if (got) *got = kVec; return j;
-            }
-            if (want == kVecAny && !vany_q_.empty()) { PlaneJob* j = vany_q_.front(); vany_q_.pop_front(); return j; }
-            if (want == kAny && !vany_q_.empty() && vany_sessions_ < vany_sessions_max()) {
-                PlaneJob* j = vany_q_.front(); vany_q_.pop_front(); vany_sessions_++; if (got) *got = kVecAny; return j;
             }
             if (want == kVecEnc && !venc_q_.empty()) { PlaneJob* j = venc_q_.front(); venc_q_.pop_front(); return j; }
             if (want == kAny && !venc_q_.empty() && venc_sessions_ < venc_sessions_max()) {
@@ -1696,6 +1640,7 @@ private:
     }
 public:
     double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
+    void set_steal_idle_test(int workers) { std::lock_guard<std::mutex> lk(mu_); steal_idle_test_ = workers < 0 ? 0 : workers; }
     double queue_seconds() { return queued_ns_.load() * 1e-9; }
     unsigned long streams_moved() { return moved_.load(); }
     // per loop kind (scalar encoder, scalar decoder, vector decoder, vector encoder): worker seconds spent in its block
@@ -1728,9 +1673,9 @@ private:
     // worker's loop.  A worker that finds nothing queued therefore takes over half of the streams of the fullest running
     // session, at that session's next block boundary (every 60000 symbols per stream: a millisecond or so): the session's
     // owner packs them up (offer), the idle worker adopts them (next) -- same kind of loop, same bytes, the streams only
-    // change threads between two blocks.  WR_POOL_STEAL=0 turns it off.
+    // change threads between two blocks.
     struct Tag { PlaneJob* job; double t0; };
-    static constexpr int kSessionTags = 2 * kVecLanes;  // streams a session can hold (two 16-lane groups)
+    static constexpr int kSessionTags = kVecLanes;  // streams a session can hold
     struct Handoff {
         int kind = kAny;
         std::vector<DecStream> dec;
@@ -1741,11 +1686,10 @@ private:
     std::deque<Handoff> handoff_;
     int thieves_ = 0;            // workers waiting with nothing queued for them (mu_)
     std::vector<int> lanes_;     // streams in every worker's running session, by worker index (mu_)
-    const bool steal_ = !(getenv("WR_POOL_STEAL") && !atoi(getenv("WR_POOL_STEAL")));
-    const int steal_idle_env_ = getenv("WR_POOL_STEAL_IDLE") ? atoi(getenv("WR_POOL_STEAL_IDLE")) : 0;
+    int steal_idle_test_ = 0;    // tests: this many idle workers are enough for a hand-over (pool_test_steal_idle_min; 0: the rule below)
     int steal_idle_min() const  // mu_ held
     {
-        if (steal_idle_env_ > 0) return steal_idle_env_;
+        if (steal_idle_test_ > 0) return steal_idle_test_;
         const int w = (int)workers_.size();
         return w < 4 ? 1 : (w + 3) / 4;
     }
@@ -1764,7 +1708,7 @@ private:
             if (*j) return true;
             std::unique_lock<std::mutex> lk(mu_);
             if (!handoff_.empty()) { *h = std::move(handoff_.front()); handoff_.pop_front(); *kind = h->kind; return true; }
-            if (!(vec_q_.empty() && venc_q_.empty() && vany_q_.empty() && dec_q_.empty() && enc_q_.empty()) && startable()) continue;
+            if (!(vec_q_.empty() && venc_q_.empty() && dec_q_.empty() && enc_q_.empty()) && startable()) continue;
             if (stop_) return false;
             const double t = now_s();
             thieves_++;
@@ -1776,7 +1720,7 @@ private:
     // something queued that a worker without a session may start now (mu_ held)
     bool startable() const
     {
-        return (!vec_q_.empty() && vec_sessions_ < vec_sessions_max()) || (!vany_q_.empty() && vany_sessions_ < vany_sessions_max()) ||
+        return (!vec_q_.empty() && vec_sessions_ < vec_sessions_max()) ||
                (!venc_q_.empty() && venc_sessions_ < venc_sessions_max()) || !dec_q_.empty() || !enc_q_.empty();
     }
     // A session's owner, between two blocks: publishes how many streams it holds and, if a worker is waiting and no
@@ -1786,11 +1730,11 @@ private:
     {
         std::lock_guard<std::mutex> lk(mu_);
         lanes_[(size_t)id] = g.count();
-        // Only when a good part of the pool has nothing to do (WR_POOL_STEAL_IDLE, default a quarter of the workers): a
+        // Only when a good part of the pool has nothing to do (a quarter of the workers): a
         // lone caller, a short batch, the drain of a run.  In steady state with every worker busy most of the time, a
         // worker that is idle for a moment would split a well-filled session into two half-filled ones, and a 16-lane
         // loop at 8 lanes does 70 % of the work per second: measured 10.7 GB/s against 11.8 without (profiles/r03).
-        if (!steal_ || thieves_ <= (int)handoff_.size() || thieves_ < steal_idle_min() || g.count() < 2) return;
+        if (thieves_ <= (int)handoff_.size() || thieves_ < steal_idle_min() || g.count() < 2) return;
         for (int c : lanes_) if (c > g.count()) return;  // a fuller session does it at its next boundary
         Handoff h;
         h.kind = kind;
@@ -1843,13 +1787,12 @@ private:
         int dec_streams;
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
         std::unique_ptr<DecGroup> dg;
-        std::unique_ptr<VecDecGroup> vg, vag;
-        std::unique_ptr<DualVecDecGroup> dvg;
+        std::unique_ptr<VecDecGroup> vg;
         std::unique_ptr<VecEncGroup> veg;
         EncGroup eg;
         Tag tags[kSessionTags];
         auto add_dec = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->src_len, j->dst, j->n, t, j->io); };
-        auto add_enc = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->n, j->dst, j->hist, t, j->io); };
+        auto add_enc = [](auto& g, PlaneJob* j, Tag* t) { g.add(j->src, j->n, j->dst, j->hist, t, j->io, j->dst_limit); };
         auto adopt_dec = [](auto& g, Handoff& h, size_t i, Tag* t) { g.take(std::move(h.dec[i])); g.set_tag_of_last(t); };
         auto adopt_enc = [](auto& g, Handoff& h, size_t i, Tag* t) { g.take(h.enc[i]); g.set_tag_of_last(t); };
         auto pack_dec = [](auto& g, Handoff* h) {
@@ -1872,18 +1815,10 @@ private:
             if (!next(&kind, &j, &h)) return;
             for (Tag& t : tags) t.job = nullptr;
             const bool counted = j != nullptr;  // a session started from a queue counts against its kind's cap (pop)
-            if (kind == kVec && kVecDual) {
-                if (!dvg) dvg.reset(new DualVecDecGroup);
-                session(id, kVec, 2, *dvg, j, h, tags, add_dec, adopt_dec, pack_dec);
-                session_over(id, counted ? &vec_sessions_ : nullptr);
-            } else if (kind == kVec) {
+            if (kind == kVec) {
                 if (!vg) vg.reset(new VecDecGroup);
                 session(id, kVec, 2, *vg, j, h, tags, add_dec, adopt_dec, pack_dec);
                 session_over(id, counted ? &vec_sessions_ : nullptr);
-            } else if (kind == kVecAny) {
-                if (!vag) vag.reset(new VecDecGroup(true));
-                session(id, kVecAny, 4, *vag, j, h, tags, add_dec, adopt_dec, pack_dec);
-                session_over(id, counted ? &vany_sessions_ : nullptr);
             } else if (kind == kVecEnc) {
                 if (!veg) veg.reset(new VecEncGroup);
                 session(id, kVecEnc, 3, *veg, j, h, tags, add_enc, adopt_enc, pack_enc);
@@ -1902,41 +1837,28 @@ private:
 
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_, vany_q_;
-    // WR_VEC_ANY=1: decoder planes without dominant symbols (noise planes) take the 16-lane loop for planes of any
-    // statistics instead of the scalar loops of up to four; WR_VEC_ANY_SESSIONS workers at most run such a session at a
-    // time (default: an eighth of the workers, at least one).  Opt-in: EPYC 9575F, one thread, noise planes: 438 Msym/s
-    // with 16 lanes against 323 in the scalar loop of four, but every stream in it advances at 27 Msym/s against 81
-    // (profiles/r03/h_rc_any_epyc9575f.txt), and with the fields in flight bounded by memory it is the slowest stream of
-    // a field that sets the rate.
-    const bool vec_any_ = getenv("WR_VEC_ANY") && atoi(getenv("WR_VEC_ANY"));
-    int vany_sessions_ = 0;
-    const int vany_sessions_env_ = getenv("WR_VEC_ANY_SESSIONS") ? atoi(getenv("WR_VEC_ANY_SESSIONS")) : 0;
-    int vany_sessions_max() const  // call with mu_ held
-    {
-        if (vany_sessions_env_ > 0) return vany_sessions_env_;
-        const int w = (int)workers_.size();
-        return w < 8 ? 1 : (w + 4) / 8;
-    }
+    std::deque<PlaneJob*> enc_q_, dec_q_, vec_q_, venc_q_;
+    // (A 16-lane decoder loop for planes of ANY statistics -- range / 60000 by multiply-shift, low / help by vdivpd, the two
+    // table look-ups as scalar loads per lane -- was built, bit-exact, and lost: 438 Msym/s per worker against 323 in the scalar
+    // loop of four on noise planes, but every stream in it advances at 27 Msym/s against 81, and with the fields in flight
+    // bounded by memory it is the slowest stream of a field that sets the rate: 4.4 against 11.8 GB/s.  Removed in round 5;
+    // profiles/r03/h_rc_any_epyc9575f.txt, i_bench_*)
     // The encoder's vector loop takes every plane (WR_VEC_ENCODE=0: scalar loops of three instead): 16 planes at 1.0-1.3
     // Gsym/s per worker in the pipeline against 0.56 in the scalar loops.  Per stream it advances at 75-150 Msym/s against
-    // ~190, so the sessions are kept as many as leave a field's encode no longer than its decode (WR_VEC_ENC_SESSIONS;
-    // default 3/8 of the workers: 16 workers, 24 fields in flight: 6 sessions 11.3 GB/s, 4 sessions 9.4, scalar 9.4-9.7).
+    // ~190, so the sessions are kept as many as leave a field's encode no longer than its decode (3/8 of the workers:
+    // 16 workers, 24 fields in flight: 6 sessions 11.3 GB/s, 4 sessions 9.4, scalar 9.4-9.7; 4 + 5, 4 + 6, 5 + 5 encoder +
+    // decoder sessions instead of 6 + 5: the same within the run-to-run spread, profiles/r03/be_sessions_*).
     const bool vec_enc_ = !(getenv("WR_VEC_ENCODE") && !atoi(getenv("WR_VEC_ENCODE")));
     int venc_sessions_ = 0;
-    const int venc_sessions_env_ = getenv("WR_VEC_ENC_SESSIONS") ? atoi(getenv("WR_VEC_ENC_SESSIONS")) : 0;
     int venc_sessions_max() const  // call with mu_ held
     {
-        if (venc_sessions_env_ > 0) return venc_sessions_env_;
         const int w = (int)workers_.size();
         return w < 3 ? 1 : (w * 3 + 4) / 8;
     }
     const bool vec_ok_ = vec_available();
     int vec_sessions_ = 0;
-    const int vec_sessions_env_ = getenv("WR_VEC_SESSIONS") ? atoi(getenv("WR_VEC_SESSIONS")) : 0;
     int vec_sessions_max() const  // call with mu_ held
     {
-        if (vec_sessions_env_ > 0) return vec_sessions_env_;
         const int w = (int)workers_.size();
         return w < 4 ? 1 : (w * 5 + 8) / 16;  // 16 workers: 5 sessions (with the vector encoder: 11.3 GB/s; 3 sessions: 10.1)
     }
@@ -1948,6 +1870,7 @@ private:
 }  // namespace
 
 void pool_configure(int nthreads, int dec_streams) { Pool::get().resize(nthreads, dec_streams); }
+void pool_test_steal_idle_min(int workers) { Pool::get().set_steal_idle_test(workers); }
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
 double pool_queue_seconds() { return Pool::get().queue_seconds(); }

@@ -31,6 +31,9 @@ size_t encode_bound_hist(const uint16_t* hists, size_t n);
 //   encoder: the symbols [first, first + count); the pointer stays valid until the next call.
 //   decoder: room for the symbols [first, first + count); the window handed out before is complete by then.  A call
 //            with *count == 0 ends the stream (the last window is complete; nothing is handed back).
+// REFUSAL: a request for symbols (*count != 0 on entry) that comes back with a null pointer has been turned down by the
+// plane's owner (a stale handle, windows out of order, two coders in one stream: wr_handover.h).  The coder then gives the
+// stream up at once -- it touches no symbol and writes nothing further -- and its result is (size_t)-1.
 struct PlaneWindow {
     uint8_t* (*window)(void* user, size_t first, size_t* count);
     void* user;
@@ -38,14 +41,18 @@ struct PlaneWindow {
 
 // Encode n symbols; `out` must hold encode_bound(n) bytes.  `hists`, when non-null, holds
 // per-block byte histograms (uint16[256] per block, n/60000+1 blocks) computed on the GPU.
-// Returns the stream length.
+// Returns the stream length, (size_t)-1 if the stream was given up (a refused window; histograms that are not the plane's:
+// they do not add up to a block, or a symbol they count zero times turns up -- at most kFailedBlockSlack bytes beyond what
+// encode_bound_hist says have been written by then).
+constexpr size_t kFailedBlockSlack = 131072;  // one block at 2 bytes per symbol + its header
 size_t encode_plane(const uint8_t* sym, size_t n, uint8_t* out, const uint16_t* hists);
 
 // `count` planes of n symbols each on the calling thread, their symbol loops interleaved in
 // groups of up to kMaxStreams (same bytes as encode_plane on each).  hists may be null, and so
 // may its entries.
 void encode_planes(int count, const uint8_t* const* sym, size_t n, uint8_t* const* out, const uint16_t* const* hists, size_t* lens,
-                   const PlaneWindow* const* io = nullptr);  // io[k] non-null: plane k comes through windows, sym[k] is ignored
+                   const PlaneWindow* const* io = nullptr,  // io[k] non-null: plane k comes through windows, sym[k] is ignored
+                   const size_t* limits = nullptr);         // limits[k]: encode_bound_hist of plane k's histograms (see PlaneJob::dst_limit)
 
 // Decode a stream into exactly n symbols.  Returns the number of symbols the stream held
 // (== n for a well-formed stream; never writes more than n symbols, never reads past len).
@@ -58,10 +65,8 @@ void decode_planes(int count, const uint8_t* const* in, const size_t* len, uint8
 
 // `count` dominant-symbol planes (any lengths) on the calling thread, up to 16 at a time in the AVX-512 loop
 // (wr_rangecoder_vec.h); false if the CPU lacks AVX-512.  Same symbols as decode_plane on each.
-// any: through the loop for planes of any statistics (division and table look-ups per lane: what noise planes need)
-// instead of the candidate-compare loop.
 bool decode_planes_vec(int count, const uint8_t* const* in, const size_t* len, uint8_t* const* sym, const size_t* n, size_t* produced,
-                       const PlaneWindow* const* io = nullptr, bool any = false);
+                       const PlaneWindow* const* io = nullptr);
 
 // `count` planes of any kind on the calling thread, up to 16 at a time in the AVX-512 encoder loop; false if the CPU
 // lacks AVX-512.  Same bytes as encode_plane on each.
@@ -85,16 +90,19 @@ struct PlaneJob {
     uint8_t* dst = nullptr;        // encode: encode_bound(n) bytes; decode: n symbols
     size_t n = 0;
     const uint16_t* hist = nullptr;  // encode: per-block histograms from the GPU, or null
+    size_t dst_limit = 0;            // encode with `hist`: encode_bound_hist(hist, n) -- the stream is given up once it is longer than its own
+                                     // histograms allow (they are not this plane's); dst then holds dst_limit + kFailedBlockSlack bytes.  0: no check
     const PlaneWindow* io = nullptr; // the symbol side (encode: src, decode: dst) comes / goes through windows instead
-    size_t result = 0;             // encode: stream length; decode: symbols the stream held, (size_t)-1 if undecodable
+    size_t result = 0;             // encode: stream length, (size_t)-1 if given up; decode: symbols the stream held, (size_t)-1 if undecodable or given up
     double seconds = 0;            // from the moment a worker took the job to its end
     double submitted = 0;          // (pool) when the job was queued
     JobBatch* batch = nullptr;
 };
 void pool_configure(int nthreads, int dec_streams);  // nthreads = 0 stops the pool; dec_streams < 1 keeps the setting
+void pool_test_steal_idle_min(int workers);  // native tests: a hand-over of streams needs only this many idle workers (0: the product's rule)
 int pool_threads();
-constexpr int kLoopKinds = 5;
-// per loop kind {scalar enc, scalar dec, vector dec (dominant symbols), vector enc, vector dec (any statistics)}: worker seconds in block steps, stream-blocks advanced
+constexpr int kLoopKinds = 4;
+// per loop kind {scalar enc, scalar dec, vector dec (dominant symbols), vector enc}: worker seconds in block steps, stream-blocks advanced
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]);
 unsigned long pool_streams_moved();  // streams that changed workers between two blocks (an idle worker took over half of the fullest session)
 double pool_queue_seconds();  // time jobs have waited in the pool's queues before a worker took them, summed over jobs

@@ -214,151 +214,15 @@ void vec_decode_block(VecBlock* b, VecOther other)
     s.fini(m);
 }
 
-// Two blocks at once, their steps interleaved: a step is a dependency chain of ~45 cycles (compare -> mask -> shift,
-// multiply-shift division, candidate products, compare -> mask -> dependent selects) that leaves most of the core's vector
-// issue slots empty; the second group's chain runs in them.
-void vec_decode_block2(VecBlock* b0, VecBlock* b1, VecOther other)
-{
-    DecLanes s0, s1;
-    DecMem m0, m1;
-    s0.init(m0, b0, other);
-    s1.init(m1, b1, other);
-    for (uint32_t i = 0; i < kBlockSyms; i++) { s0.step(m0, i); s1.step(m1, i); }
-    s0.fini(m0);
-    s1.fini(m1);
-}
-
-void vec_decode_block_any(VecAnyBlock* b)
-{
-    const __mmask16 act = (__mmask16)b->active;
-    const __m512i vbottom = _mm512_set1_epi32((int)kBottom);
-    __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
-    __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
-    const __m512i magic = _mm512_set1_epi64(146601551);  // see vec_decode_block
-    const __m512i hi32 = _mm512_set1_epi64((long long)0xFFFFFFFF00000000ull);
-    const __m512i lo16 = _mm512_set1_epi32(0xffff);
-    const uint8_t* const lookup = b->lookup;
-    uint32_t* const packed = b->packed;
-    // idle lanes: low stays 0, so their cumulative frequency is 0; entry 0 = {lt 0, sy 60000} keeps their range where it
-    // is (range / 60000 * 60000 is a fixed point after the first step) and above Bottom: they never renormalise
-    for (int j = 0; j < kVecLanes; j++)
-        if (!(act >> j & 1)) { b->lookup[(size_t)j * kAnyStride] = 0; packed[j * 256] = kBlockSyms << 16; }
-
-    // byte feed: as in vec_decode_block
-    const uint8_t* pw[kVecLanes];
-    uint8_t* d[kVecLanes];
-    alignas(64) uint32_t w0[kVecLanes], w1[kVecLanes];
-    auto window_at = [](const uint8_t* q) -> uint32_t {
-        uint64_t v;
-        __builtin_memcpy(&v, q - 1, 8);
-        return (uint32_t)(__builtin_bswap64(v) >> 25);
-    };
-    for (int j = 0; j < kVecLanes; j++) {
-        pw[j] = b->ptr[j]; d[j] = b->dst[j]; w0[j] = w1[j] = 0;
-        if (act >> j & 1) { w0[j] = window_at(pw[j]); w1[j] = window_at(pw[j] + 4); }
-    }
-    __m512i win = _mm512_load_si512(w0), nxt = _mm512_load_si512(w1);
-    __m512i cnt = _mm512_set1_epi32(4);
-    const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4);
-    alignas(64) uint32_t cfb[kVecLanes];
-    alignas(64) uint8_t stage[kVecLanes][64];  // the last (up to) 64 symbols of every lane
-
-    for (uint32_t i = 0; i < kBlockSyms; i++) {
-        // ---- renormalise (rangecod.c:294-302)
-        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
-        while (sh) {  // noise planes: some lane shifts in nearly every step; a second byte: symbol probability < 1/256
-            low = _mm512_mask_or_epi32(low, sh, _mm512_slli_epi32(low, 8), _mm512_srli_epi32(win, 24));
-            range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            win = _mm512_mask_slli_epi32(win, sh, win, 8);
-            cnt = _mm512_mask_sub_epi32(cnt, sh, cnt, one);
-            const __mmask16 dry = _mm512_cmpeq_epu32_mask(cnt, _mm512_setzero_si512());
-            if (dry) {
-                win = _mm512_mask_mov_epi32(win, dry, nxt);
-                cnt = _mm512_mask_mov_epi32(cnt, dry, four);
-                unsigned m = dry & act;
-                while (m) {
-                    const int j = __builtin_ctz(m);
-                    m &= m - 1;
-                    pw[j] += 4;
-                    nxt = _mm512_mask_set1_epi32(nxt, (__mmask16)(1u << j), (int)window_at(pw[j] + 4));
-                }
-            }
-            sh = _mm512_cmple_epu32_mask(range, vbottom);
-        }
-        // ---- help = range / 60000 (rangecod.c:312)
-        const __m512i n5 = _mm512_srli_epi32(range, 5);
-        const __m512i ev = _mm512_srli_epi64(_mm512_mul_epu32(n5, magic), 38);
-        const __m512i od = _mm512_and_si512(_mm512_srli_epi64(_mm512_mul_epu32(_mm512_srli_epi64(n5, 32), magic), 6), hi32);
-        const __m512i help = _mm512_or_si512(ev, od);
-        // ---- cf = low / help (rangecod.c:313) in double precision, truncated.  Exact: low < 2^32 and help < 2^16 (range <=
-        // 2^31, / 60000) are doubles as they stand; the quotient x = low / help is below 2^32, and when it is not an integer
-        // it lies at least 1 / help >= 2^-16 away from one, while the correctly rounded double quotient is within
-        // 2^-53 x < 2^-21 of x: rounding never reaches the next integer, so the truncation is floor(low / help).
-        const __m256i q0 = _mm512_cvttpd_epu32(_mm512_div_pd(_mm512_cvtepu32_pd(_mm512_castsi512_si256(low)),
-                                                             _mm512_cvtepu32_pd(_mm512_castsi512_si256(help))));
-        const __m256i q1 = _mm512_cvttpd_epu32(_mm512_div_pd(_mm512_cvtepu32_pd(_mm512_extracti64x4_epi64(low, 1)),
-                                                             _mm512_cvtepu32_pd(_mm512_extracti64x4_epi64(help, 1))));
-        _mm256_store_si256(reinterpret_cast<__m256i*>(cfb), q0);
-        _mm256_store_si256(reinterpret_cast<__m256i*>(cfb + 8), q1);
-        // ---- the symbol of cf and its {lt, sy}: two dependent loads per lane; the symbol goes to the lane's staging row,
-        // the packed entry into a vector by inserts (sixteen narrow stores read back by one wide load would have to
-        // wait for the stores to retire)
-        const uint32_t col = i & 63;
-        __m128i x[4];
-#pragma GCC unroll 4
-        for (int g = 0; g < 4; g++) {
-            uint32_t e[4];
-#pragma GCC unroll 4
-            for (int k = 0; k < 4; k++) {
-                const int j = 4 * g + k;
-                const uint32_t c = lookup[(size_t)j * kAnyStride + cfb[j]];
-                stage[j][col] = (uint8_t)c;
-                e[k] = packed[j * 256 + c];
-            }
-            x[g] = _mm_insert_epi32(_mm_insert_epi32(_mm_insert_epi32(_mm_cvtsi32_si128((int)e[0]), (int)e[1], 1), (int)e[2], 2), (int)e[3], 3);
-        }
-        const __m512i ent = _mm512_inserti64x4(_mm512_castsi256_si512(_mm256_inserti128_si256(_mm256_castsi128_si256(x[0]), x[1], 1)),
-                                               _mm256_inserti128_si256(_mm256_castsi128_si256(x[2]), x[3], 1), 1);
-        // ---- rangecod.c:339-351: low -= help * lt; range = help * sy, or what is left of it for the largest symbol
-        const __m512i lt = _mm512_and_si512(ent, lo16), sy = _mm512_srli_epi32(ent, 16);
-        const __m512i t = _mm512_mullo_epi32(help, lt);
-        const __mmask16 is_top = _mm512_cmpeq_epu32_mask(sy, _mm512_setzero_si512());
-        low = _mm512_sub_epi32(low, t);
-        range = _mm512_mask_sub_epi32(_mm512_mullo_epi32(help, sy), is_top, range, t);
-        // ---- symbols out: 64 per lane at a time
-        if (col == 63) {
-            unsigned m = act;
-            while (m) {
-                const int j = __builtin_ctz(m);
-                m &= m - 1;
-                _mm512_storeu_si512(d[j] + (i - 63), _mm512_load_si512(stage[j]));
-            }
-        }
-    }
-    {   // 60000 = 937 * 64 + 32: the last 32 symbols of every lane
-        constexpr uint32_t done = kBlockSyms / 64 * 64, rest = kBlockSyms - done;
-        unsigned m = act;
-        while (m) {
-            const int j = __builtin_ctz(m);
-            m &= m - 1;
-            memcpy(d[j] + done, stage[j], rest);
-        }
-    }
-    _mm512_mask_storeu_epi32(b->low, act, low);
-    _mm512_mask_storeu_epi32(b->range, act, range);
-    alignas(64) uint32_t left[kVecLanes];
-    _mm512_store_si512(left, cnt);
-    for (int j = 0; j < kVecLanes; j++)
-        if (act >> j & 1) b->ptr[j] = pw[j] + (4 - left[j]);
-}
-
-// MODE 0: {lt, sy} by comparing with the lane's candidates; 1: two 8-lane gathers from the lanes' tables; 2: a scalar load per
-// lane from the lanes' packed tables, returned to a vector by inserts (the symbols then come straight from the lanes'
-// streams, no transposes) -- AMD's gathers are microcoded: EPYC 9575F, 16 noise planes, one thread: see profiles/r03
+// MODE 0: {lt, sy} by comparing with the lane's candidates; 2: a scalar load per lane from the lanes' packed tables, returned
+// to a vector by inserts (the symbols then come straight from the lanes' streams, no transposes).  (1 was two 8-lane gathers
+// from the lanes' tables: AMD's gathers are microcoded, EPYC 9575F, 16 noise planes, one thread: 0.93 against 1.09 Gsym/s,
+// profiles/r03; removed.)
 template <bool ALWAYS, int MODE>
 static void vec_encode_block_t(VecEncBlock* b)
 {
-    const __mmask16 act = (__mmask16)b->active;
+    static_assert(MODE == 0 || MODE == 2, "candidate compares or per-lane look-ups");
+    __mmask16 act = (__mmask16)b->active;
     const __m512i vbottom = _mm512_set1_epi32((int)kBottom), vtopm1 = _mm512_set1_epi32((int)(kTop - 1));
     __m512i low = _mm512_maskz_loadu_epi32(act, b->low);
     __m512i range = _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kTop), act, b->range);
@@ -372,9 +236,6 @@ static void vec_encode_block_t(VecEncBlock* b)
         csy[e] = e == 0 ? _mm512_mask_loadu_epi32(_mm512_set1_epi32((int)kBlockSyms), act, b->sy[e]) : _mm512_maskz_loadu_epi32(act, b->sy[e]);
     }
     const __m512i one = _mm512_set1_epi32(1), four = _mm512_set1_epi32(4), v255 = _mm512_set1_epi32(0xff);
-    const __m512i lane_base = _mm512_setr_epi32(0, 256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304, 2560, 2816, 3072, 3328, 3584, 3840);
-    const __m512i pick_even = _mm512_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30);
-    const __m512i pick_odd = _mm512_setr_epi32(1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31);
     // byte swap inside every 32-bit lane (vpshufb works per 128-bit lane; the pattern repeats)
     const __m512i bswap = _mm512_broadcast_i32x4(_mm_set_epi8(12, 13, 14, 15, 8, 9, 10, 11, 4, 5, 6, 7, 0, 1, 2, 3));
 
@@ -410,6 +271,35 @@ static void vec_encode_block_t(VecEncBlock* b)
     __m512i held = _mm512_load_si512(hbuf), ffs = _mm512_load_si512(fbuf);
     __m512i pend = _mm512_setzero_si512(), cnt = _mm512_setzero_si512();
     __m128i rows[16];
+
+    // Lanes whose range has gone to ZERO: their table counted the symbol they just coded zero times -- it is not the table
+    // of these symbols (VecEncBlock::failed).  Such a lane would shift bytes out for ever; it is retired instead: from here
+    // on it is an idle lane (symbol 0 with {lt 0, sy 60000} for ever, stores into `dummy`), and the caller gives its stream up.
+    auto retire_lanes = [&](unsigned m) {
+        const __mmask16 k = (__mmask16)m;
+        b->failed |= m;
+        act = (__mmask16)(act & ~m);
+        range = _mm512_mask_mov_epi32(range, k, _mm512_set1_epi32((int)kTop));
+        low = _mm512_maskz_mov_epi32((__mmask16)~k, low);
+        held = _mm512_maskz_mov_epi32((__mmask16)~k, held);
+        ffs = _mm512_maskz_mov_epi32((__mmask16)~k, ffs);
+        pend = _mm512_maskz_mov_epi32((__mmask16)~k, pend);
+        cnt = _mm512_maskz_mov_epi32((__mmask16)~k, cnt);
+        const __m512i vdummy = _mm512_set1_epi64((long long)(uintptr_t)dummy);
+        alo = _mm512_mask_mov_epi64(alo, (__mmask8)(m & 0xff), vdummy);
+        ahi = _mm512_mask_mov_epi64(ahi, (__mmask8)(m >> 8), vdummy);
+        for (int e = 0; e < kVecCand; e++) {
+            cand[e] = _mm512_mask_mov_epi32(cand[e], k, _mm512_set1_epi32(0x100));
+            clt[e] = _mm512_maskz_mov_epi32((__mmask16)~k, clt[e]);
+            csy[e] = e == 0 ? _mm512_mask_mov_epi32(csy[e], k, _mm512_set1_epi32((int)kBlockSyms)) : _mm512_maskz_mov_epi32((__mmask16)~k, csy[e]);
+        }
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            in[j] = zeros; step_of[j] = 0;
+            if (MODE == 2) b->packed[j * 256] = kBlockSyms << 16;
+        }
+    };
 
     auto flush_all = [&]() {
         // first byte out in the most significant position, then byte-swapped: it lands at the lowest address
@@ -475,13 +365,7 @@ static void vec_encode_block_t(VecEncBlock* b)
                                                    _mm256_inserti128_si256(_mm256_castsi128_si256(x[2]), x[3], 1), 1);
             lt = _mm512_and_si512(ent, _mm512_set1_epi32(0xffff));
             sy = _mm512_srli_epi32(ent, 16);
-            is_top_m = _mm512_cmpeq_epu32_mask(sy, _mm512_setzero_si512());
-        } else if (MODE == 1) {
-            const __m512i idx = _mm512_add_epi32(c, lane_base);  // lane * 256 + symbol: index of the 8-byte {lt, sy} entry
-            const __m512i p0 = _mm512_i32gather_epi64(_mm512_castsi512_si256(idx), b->tab, 8);
-            const __m512i p1 = _mm512_i32gather_epi64(_mm512_extracti64x4_epi64(idx, 1), b->tab, 8);
-            lt = _mm512_permutex2var_epi32(p0, pick_even, p1);
-            sy = _mm512_permutex2var_epi32(p0, pick_odd, p1);
+            is_top_m = _mm512_cmpeq_epu32_mask(sy, _mm512_set1_epi32((int)kVecTopMark));
         } else {
             const __mmask16 k1 = _mm512_cmpeq_epu32_mask(c, cand[1]), k2 = _mm512_cmpeq_epu32_mask(c, cand[2]), k3 = _mm512_cmpeq_epu32_mask(c, cand[3]);
             const __mmask16 k0 = _mm512_cmpeq_epu32_mask(c, cand[0]);
@@ -503,14 +387,16 @@ static void vec_encode_block_t(VecEncBlock* b)
         // (ALWAYS: the step's renormalisation runs whether or not a lane shifts -- on planes of a bit per symbol some lane
         // does in most steps, unpredictably, and the branch costs more than the dozen masked instructions)
         // The masks stay in mask registers: `& act` on them went through a general register and back, on the range's
-        // chain in every step.  Idle lanes never renormalise (above); the gather form's idle lanes read a zero table and do.
-        __mmask16 sh = MODE == 1 ? _mm512_mask_cmple_epu32_mask(act, range, vbottom) : _mm512_cmple_epu32_mask(range, vbottom);
+        // chain in every step.  Idle lanes never renormalise (above).
+        __mmask16 sh = _mm512_cmple_epu32_mask(range, vbottom);
         // r = range / 60000 of the range after renormalisation is worked out for the range as it is and for the range
         // shifted, beside the compare; the compare's mask picks one (see DecLanes::step).  A second round: divide afterwards.
         const __mmask16 sh0 = sh;
         const __m512i r_as_is = div60000(range), r_shifted = div60000(_mm512_slli_epi32(range, 8));
         int rounds = 0;
         while (ALWAYS || sh) {
+            // a range of 1 or more is above Bottom after three bytes: a lane that wants a fourth has a range of zero
+            if (__builtin_expect(rounds == 3, 0)) { retire_lanes((unsigned)sh); break; }
             rounds++;
             if (__builtin_expect(_mm512_cmpeq_epu32_mask(cnt, four) != 0, 0)) flush_all();
             const __m512i v9 = _mm512_srli_epi32(low, 23);                 // carry bit (bit 8) + byte
@@ -531,7 +417,7 @@ static void vec_encode_block_t(VecEncBlock* b)
             ffs = _mm512_mask_add_epi32(ffs, isff, ffs, one);
             low = _mm512_mask_and_epi32(low, sh, _mm512_slli_epi32(low, 8), vtopm1);
             range = _mm512_mask_slli_epi32(range, sh, range, 8);
-            sh = MODE == 1 ? _mm512_mask_cmple_epu32_mask(act, range, vbottom) : _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256
+            sh = _mm512_cmple_epu32_mask(range, vbottom);  // a second byte: symbol probability < 1/256
             if (ALWAYS && __builtin_expect(_kortestz_mask16_u8(sh, sh), 1)) break;
         }
         // ---- r = range / 60000; low += r * lt; range = r * sy, or what is left for the largest symbol (rangecod.c:217-229)
@@ -551,7 +437,7 @@ static void vec_encode_block_t(VecEncBlock* b)
     _mm512_store_si512(hbuf, held);
     _mm512_store_si512(fbuf, ffs);
     for (int j = 0; j < kVecLanes; j++) {
-        if (!(act >> j & 1)) continue;
+        if (!(act >> j & 1)) continue;  // (idle and retired lanes)
         uint8_t* p = reinterpret_cast<uint8_t*>((uintptr_t)addr[j]);
         *p++ = (uint8_t)hbuf[j];
         for (uint32_t k = 0; k < fbuf[j]; k++) *p++ = 0xff;
@@ -570,8 +456,8 @@ void vec_encode_block(VecEncBlock* b)
         for (int e = 0; e < kVecCand; e++) if (b->sy[e][j] > best) best = b->sy[e][j];
         if ((uint64_t)best * 100 < (uint64_t)kBlockSyms * 97) busy++;
     }
-    static const bool use_gathers = getenv("WR_VEC_ENC_GATHER") && atoi(getenv("WR_VEC_ENC_GATHER"));
-    if (b->gather) { if (use_gathers) vec_encode_block_t<true, 1>(b); else vec_encode_block_t<true, 2>(b); }
+    b->failed = 0;
+    if (b->gather) vec_encode_block_t<true, 2>(b);
     else if (busy >= 2) vec_encode_block_t<true, 0>(b);
     else vec_encode_block_t<false, 0>(b);
 }

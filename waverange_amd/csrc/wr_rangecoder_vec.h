@@ -15,6 +15,7 @@ namespace wrrc {
 
 constexpr int kVecLanes = 16;
 constexpr int kVecCand = 4;
+constexpr uint32_t kVecTopMark = 0xffffu;  // VecEncBlock::packed: the count field of the largest symbol present (counts are <= 60000)
 
 // One full block (60000 symbols) of up to 16 streams.  Lane state in, lane state out.
 struct VecBlock {
@@ -34,11 +35,13 @@ typedef uint32_t (*VecOther)(const void* model, uint32_t* low, uint32_t* range, 
 // One full block (60000 symbols) of up to 16 ENCODER streams.  The encoder's dependency chain is only renormalise ->
 // range / 60000 -> new range (rangecod.c:182-229).  The symbol's {lt, sy} come from four compares against the lane's
 // most probable symbols while every lane's block is held by at most four symbols (all but a per cent or less; a symbol
-// outside them takes a scalar table look-up on that lane), or (`gather`) from two 8-lane gathers into the lanes' tables:
-// planes of any statistics.  The last byte shifted out and the 0xff bytes behind it are held back per lane until the
+// outside them takes a scalar table look-up on that lane), or (`gather`) from a scalar load per lane out of the lanes' packed
+// tables, returned to a vector by inserts: planes of any statistics (AMD's gathers are microcoded and slower).  The last byte shifted out and the 0xff bytes behind it are held back per lane until the
 // next byte decides about a carry (rangecod.c:182-207); final bytes leave in packed 4-byte stores.
 struct VecEncBlock {
     uint32_t active;                 // lane mask
+    uint32_t failed;                 // out: lanes retired inside the block -- their table counted a symbol zero times (the lane's
+                                     // range went to zero): nothing of them is handed back, at most a byte per symbol was written
     uint32_t low[kVecLanes], range[kVecLanes];
     const uint8_t* sym[kVecLanes];   // 60000 symbols each
     uint8_t* out[kVecLanes];         // stream buffers
@@ -47,32 +50,13 @@ struct VecEncBlock {
     const uint32_t* tab;             // [16 lanes][256 symbols]{lt, sy}: symbols outside the candidates
     uint32_t top[kVecLanes];         // largest symbol present: its interval is open-ended (rangecod.c:227)
     int gather;                      // != 0: {lt, sy} of every symbol looked up per lane (lanes with any statistics); else candidates
-    uint32_t* packed;                // gather mode: [16 lanes][256 symbols] lt | sy << 16, sy = 0 marking the largest symbol present
-                                     // (filled by the caller for the active lanes; entry 0 of idle lanes is overwritten)
+    uint32_t* packed;                // gather mode: [16 lanes][256 symbols] lt | sy << 16, sy = kVecTopMark marking the largest symbol
+                                     // present (a count of ZERO is a symbol the table does not know: coding one retires the lane);
+                                     // filled by the caller for the active lanes; entry 0 of idle lanes is overwritten
 };
 void vec_encode_block(VecEncBlock* b);
 
-// One full block (60000 symbols) of up to 16 decoder streams with ANY statistics (noise planes: ~7 bits per symbol, no
-// dominant symbols to compare with).  The step needs the reference's two divisions (rangecod.c:312-313): range / 60000
-// is a multiply-shift, low / help is done in double precision, 8 lanes per vdivpd -- exact, see the proof at the loop --
-// and its two table look-ups (symbol of a cumulative frequency, then {lt, sy} of the symbol), which stay scalar loads per
-// lane (the 60 KB tables of 16 lanes are 1 MB: they live in L2; AMD's gathers are microcoded and slower than 16 loads)
-// whose results return to a vector by inserts, not through memory.  ~9 instructions per symbol against ~35 in the
-// scalar loop of four (wr_rangecoder.cpp, decode_symbols_multi).
-constexpr uint32_t kAnyStride = 60544;  // kBlock + 512 (see decode_symbols: cf < tot + 430) rounded up to 64
-struct VecAnyBlock {
-    uint32_t active;                 // lane mask
-    uint32_t low[kVecLanes], range[kVecLanes];
-    const uint8_t* ptr[kVecLanes];   // next unread stream byte; ptr[-1] is the byte held back (rangecod.c:297-299)
-    uint8_t* dst[kVecLanes];         // 60000 symbols each
-    uint8_t* lookup;                 // [16][kAnyStride]: symbol of every cumulative frequency, padded with the largest symbol
-    uint32_t* packed;                // [16][256]: lt | sy << 16, sy = 0 marking the largest symbol present (open-ended
-                                     // interval, rangecod.c:345-348); entry 0 of idle lanes is overwritten
-};
-void vec_decode_block_any(VecAnyBlock* b);
-
 bool vec_available();  // the CPU has AVX-512 F/BW/DQ/VL and WR_NO_AVX512 is not set
 void vec_decode_block(VecBlock* b, VecOther other);
-void vec_decode_block2(VecBlock* b0, VecBlock* b1, VecOther other);  // two blocks, steps interleaved
 
 }  // namespace wrrc
