@@ -253,8 +253,11 @@ int wr_dev_synth_field(wr_ctx *ctx, double *d_out, int nx, int ny, int nz,
                        unsigned long long seed);
 
 /* --- device-only part of the codec (no range coder): transform + all quantizer planes.
- * d_fld is consumed (holds the residual afterwards).  d_planes receives nlay planes at a
- * pitch of wr_plane_pitch(n) bytes.  Fills tolabs/midval/halfspanval/wlev/nlay/deps/minval. */
+ * d_fld is CONSUMED: with wr_ctx_set_keep_residual(ctx, 1) it holds the residual in wavelet space afterwards (what the
+ * reference leaves in fld_1d, wrappers.cpp:397-398); without, its contents are unspecified (since round 4 the planes are cut
+ * from residuals recomputed from the coefficient array, which nobody writes back: the array then holds the coefficients).
+ * The same goes for d_fld of wr_encode_device.  d_planes receives nlay planes at a pitch of wr_plane_pitch(n) bytes.
+ * Fills tolabs/midval/halfspanval/wlev/nlay/deps/minval. */
 size_t wr_plane_pitch(size_t n);
 int wr_dev_encode_planes(wr_ctx *ctx, double *d_fld, int nx, int ny, int nz, int wtflag,
                          double tolrel, unsigned char *d_planes, wr_enc_info *info);

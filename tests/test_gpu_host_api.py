@@ -192,8 +192,10 @@ def test_config4_sharded_fields_container_vs_oracle(oracle, tmp_path, n):
     """BASELINE configs[3]: NF = 8 independent 512^3 fp64 fields (seeds 12345..12352) coded by the launchable sharded
     encoder -- python -m torch.distributed.run ... -m waverange_amd.sharded, two ranks here (both on this
     box's one GPU; on an 8-GPU node the same command runs with 8) -- and the .wrh / .wrb pair compared byte for
-    byte with the container assembled from the oracle-coded fields.  The 512^3 case IS config 4; it is skipped -- visibly,
-    with the free space in the reason -- when the scratch disk cannot hold its 8.6 GB input; the 256^3 case always runs."""
+    byte with the container assembled from the oracle-coded fields (256^3) or with what the COMPILED REFERENCE produced for
+    every one of the eight fields (512^3: tests/golden/large.json holds a pin per seed -- no minute of oracle on the GPU box).
+    The 512^3 case IS config 4; it is skipped -- visibly, with the free space in the reason -- when the scratch disk cannot
+    hold its 8.6 GB input; the 256^3 case always runs."""
     from waverange_amd import sharded
     nf = 8
     free = shutil.disk_usage(tmp_path).free
@@ -209,13 +211,20 @@ def test_config4_sharded_fields_container_vs_oracle(oracle, tmp_path, n):
             fields.append(f)
     specs = [dict(nbytes=8, nx=n, ny=n, nz=n, nh=1, idinv=0, icomp=1, tol_base=tol) for _ in range(nf)]
     encs = [None] * nf
+    pins = None
+    if n == 512:
+        from util import large_golden
+        g = large_golden()
+        pins = [g["512^3_tol1e-05" + ("" if i == 0 else "_seed%d" % (12345 + i))] for i in range(nf)]
+        for i in range(nf):
+            assert sha(fields[i]) == pins[i]["input_sha256"]
 
     def cpu(i):
         e = oracle.encode(fields[i], tol)
         del e["residual"]
         encs[i] = e
 
-    ths = [threading.Thread(target=cpu, args=(i,)) for i in range(nf)]
+    ths = [] if pins else [threading.Thread(target=cpu, args=(i,)) for i in range(nf)]
     for t in ths:
         t.start()
     env = dict(os.environ, WR_QUIET="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
@@ -226,12 +235,36 @@ def test_config4_sharded_fields_container_vs_oracle(oracle, tmp_path, n):
     for t in ths:
         t.join()
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    import hashlib
+    if pins:
+        # the header text from the reference's scalars (bit patterns), the payload of every field against the reference's hash
+        fh = float.fromhex
+        encs = [dict(tolabs=fh(p["tolabs"]), midval=fh(p["midval"]), halfspanval=fh(p["halfspanval"]), wlev=p["wlev"], nlay=p["nlay"], ntot_enc=p["ntot_enc"],
+                     deps_vec=[fh(v) for v in p["deps_vec"]], minval_vec=[fh(v) for v in p["minval_vec"]], len_enc_vec=p["len_enc_vec"]) for p in pins]
+        records = [dict(recl=bytes(8), enc=e, payload=b"") for e in encs]
+        sharded.write_container(str(tmp_path / "want.wrh"), str(tmp_path / "want_empty.wrb"), "data.wrb", specs, 2, False, records)
+        assert open(tmp_path / "data.wrh").read() == open(tmp_path / "want.wrh").read()
+        assert os.path.getsize(tmp_path / "data.wrb") == sum(p["ntot_enc"] for p in pins)
+        wrb = np.memmap(tmp_path / "data.wrb", dtype=np.uint8, mode="r")
+        off = 0
+        for i, p in enumerate(pins):
+            assert hashlib.sha256(wrb[off:off + p["ntot_enc"]]).hexdigest() == p["data_sha256"], "coded bytes of field %d differ from the reference's" % i
+            off += p["ntot_enc"]
+        del wrb
+        cmd = cmd[:cmd.index("waverange_amd.sharded") + 1] + [str(tmp_path / "data.wrb"), str(tmp_path / "data.wrh"), str(tmp_path / "datarec.bin"), "2", "0"]
+        cmd[cmd.index("29533")] = "29534"
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        got = np.memmap(tmp_path / "datarec.bin", dtype=np.float64, mode="r")
+        assert got.size == nf * n ** 3
+        for i, p in enumerate(pins):
+            assert sha(got[i * n ** 3:(i + 1) * n ** 3]) == p["decoded_sha256"], "reconstruction of field %d differs from the reference's" % i
+        return
     records = [dict(recl=bytes(8), enc={k: e[k] for k in ("tolabs", "midval", "halfspanval", "wlev", "nlay", "ntot_enc", "deps_vec",
                                                             "minval_vec", "len_enc_vec")}, payload=e["data"].tobytes()) for e in encs]
     sharded.write_container(str(tmp_path / "want.wrh"), str(tmp_path / "want.wrb"), "data.wrb", specs, 2, False, records)
     assert open(tmp_path / "data.wrh").read() == open(tmp_path / "want.wrh").read()
     assert os.path.getsize(tmp_path / "data.wrb") == sum(e["ntot_enc"] for e in encs)
-    import hashlib
 
     def file_sha(p):
         h = hashlib.sha256()

@@ -518,7 +518,9 @@ class Context:
         _check(lib().wr_dev_decode_planes(self.h, buf.ptr, nx, ny, nz, planes.ptr, C.byref(info)))
 
     def encode(self, buf, shape, tolrel, wtflag=1, out=None):
-        """Whole encode with the field resident on the device.  Returns (info dict incl. data, timings)."""
+        """Whole encode with the field resident on the device.  `buf` is consumed: it holds the residual in wavelet space
+        afterwards if set_keep_residual(True) was called on the context, otherwise its contents are unspecified.  Returns
+        (info dict incl. data, timings)."""
         nz, ny, nx = shape
         _, cap = setup_wr(nx, ny, nz)
         data = out if out is not None else np.empty(cap, dtype=np.uint8)

@@ -414,11 +414,28 @@ namespace {
 #ifndef WR_ITYP
 #define WR_ITYP 16
 #endif
-constexpr int ITYP = WR_ITYP;
-constexpr int INTHR = 32 * ITYP;
-constexpr int INWAVE = INTHR / 64;
-constexpr int HX = TXP + 4;              // coefficient columns per quadrant row (68)
-constexpr int HY = ITYP + 4;              // coefficient rows per quadrant (20)
+// Tile geometry of the inverse kernel: ITXP x ITYP coefficient pairs (2 ITXP x 2 ITYP output samples per z-plane), a wave
+// owns YPW y-pairs (RW = 2 YPW output rows).  64 x 16 with 2 y-pairs per wave is ONE workgroup of 512 threads per CU (125 KB
+// of LDS): its eight waves go through the phases of a step together; 32 x 16 with 4 y-pairs per wave is TWO workgroups of 256
+// threads per CU (2 x 67 KB), which drift apart -- one computes while the other waits at its barrier or for LDS -- at the
+// price of 6 % more halo (36 / 32 against 68 / 64 columns).  Same registers per thread either way (six chunk slots).
+#ifndef WR_ITXP
+#define WR_ITXP 64
+#endif
+#ifndef WR_YPW
+#define WR_YPW 2
+#endif
+constexpr int ITXP = WR_ITXP;            // x-pairs per tile
+constexpr int ITYP = WR_ITYP;            // y-pairs per tile
+constexpr int YPW = WR_YPW;              // y-pairs per wave
+constexpr int RW = 2 * YPW;              // output rows per wave and z-plane
+constexpr int YG = YPW / 2;              // groups of two y-pairs per wave (lift_inv_two rebuilds two pairs = four rows)
+constexpr int INWAVE = ITYP / YPW;
+constexpr int INTHR = 64 * INWAVE;
+constexpr int XCG = ITXP / 4;            // lane column groups of the x stage (four x-pairs per lane)
+static_assert(YPW % 2 == 0 && ITYP % YPW == 0 && ITXP % 4 == 0 && RW * XCG == 64 && 64 % ITXP == 0, "x stage: one lane per (row, four pairs)");
+constexpr int HX = ITXP + 4;             // coefficient columns per quadrant row (68)
+constexpr int HY = ITYP + 4;             // coefficient rows per quadrant (20)
 constexpr int CROW = HX / 2;             // 16-byte chunks per row (34)
 constexpr int NCI = 4 * HY * CROW;       // chunks per plane (2720)
 // A thread's chunk slots: the first KH cover the y-low quadrants (LL, HL), the last KH the y-high ones (LH, HH), so
@@ -432,9 +449,20 @@ constexpr int KCI = 2 * KH;              // chunk slots per thread (6)
 // give {0, 6, 10, 12} resp. {2, 4, 8, 14} slots, which the row offsets {0, 8, 1, 9} tile -- rows 9 x 128 bytes apart, the
 // upper two shifted by one piece.  (The write-back of the results, ds_write_b128 in groups of 8 lanes on 32 banks, stays
 // two-way with any offsets that serve the reads: 16 against the 13 cycles the store takes anyway.)
+// 32-pair tiles: eight rows of [xlow 36 | xhigh 36], lane = 8 * lane column + row.  By the same rules a ds_read_b128 group
+// holds rows 0-3 of lane columns {0, 3} and rows 4-7 of lane columns {1, 2} (or the other way round): with X, Y the slots
+// (16-byte pieces mod 16) rows 0-3 resp. 4-7 start in, X, Y + 2, Y + 4, X + 6 must tile the 16 slots, and so must Y, X + 2,
+// X + 4, Y + 6: X = Y = {0, 1, 8, 9} does -- row starts at 44 r + 5 (r & 1) pieces.
+#if WR_ITXP == 64
 constexpr int YPITCH = 144;              // doubles between rows
 constexpr int YWAVE = 4 * YPITCH + 16;   // doubles per wave
 __device__ inline int yrow_off(int r) { return r * YPITCH + (r >> 1) * 2; }
+#else
+static_assert(WR_ITXP == 32 && WR_YPW == 4, "row offsets of the wave-private rows are worked out for 64 x 16 / 2 and 32 x 16 / 4");
+constexpr int YPITCH = 88;
+constexpr int YWAVE = 8 * YPITCH;        // (7 x 88 + 10 + 72 = 698 doubles used)
+__device__ inline int yrow_off(int r) { return r * YPITCH + (r & 1) * 10; }
+#endif
 constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * YWAVE * 8;
 
 // whole-sample symmetric extension in coefficient space (even length 2M):
@@ -501,10 +529,10 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     double* yb = reinterpret_cast<double*>(lds2 + 2 * NCI);  // [INWAVE][YWAVE] wave-private rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
-    const int tiles_x = (m1 + TXP - 1) / TXP;
+    const int tiles_x = (m1 + ITXP - 1) / ITXP;
     int tile_x, tile_y;
     tile_of_block(blockIdx.x, tiles_x, (m2 + ITYP - 1) / ITYP, tile_x, tile_y);
-    const int px0 = tile_x * TXP, py0 = tile_y * ITYP;
+    const int px0 = tile_x * ITXP, py0 = tile_y * ITYP;
     const int z0 = blockIdx.y * zps;
     const int z1 = (z0 + zps < m3) ? z0 + zps : m3;
     const int tb = z0 >= 2 ? z0 - 2 : 0, te = z1 + 1;
@@ -516,8 +544,11 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     for (int k = 0; k < KCI; k++) {
         const int half = k / KH;                       // 0: y-low quadrants, 1: y-high quadrants
         const int ch = tid + INTHR * (k - half * KH);  // chunk inside the half
-        const int c = half * NCH + (ch < NCH ? ch : 0);
         if (ch < NCH) valid_mask |= 1u << k;
+        // (Plain row order: a quadrant row is 544 bytes that start 16 bytes before a cache line.  Taking the 512-byte cores of
+        // all rows first -- a wave's load = two whole rows = eight whole lines -- and the two halo chunks of every row
+        // afterwards was measured 5 % SLOWER, profiles/r05/c_ab_inverse_aligned_loads_same_box.txt.)
+        const int c = half * NCH + (ch < NCH ? ch : 0);
         zi[k] = c;
         const int q = c / (HY * CROW), rem = c - q * (HY * CROW);
         const int row = rem / CROW, cc = rem - row * CROW;
@@ -536,6 +567,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         const double* pll = low + (size_t)t * l_sz;
         const double* pl = src + (size_t)t * s_sz;
         const double* ph = src + (size_t)(m3 + t) * s_sz;
+        // (non-temporal loads: 5.10 against 4.15 ms -- the halo lines a neighbour tile fetches again then come from HBM; all
+        // low-z chunks before all high-z ones, non-temporal stores: within 1 %: profiles/r05/c_ab_inverse_nontemporal_*.txt)
 #pragma unroll
         for (int k = 0; k < KCI; k++) {
             if ((valid_mask >> k) & 1) {
@@ -544,14 +577,14 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
             }
         }
     };
-    const bool left_edge = px0 == 0, right_edge = px0 + TXP >= m1;
+    const bool left_edge = px0 == 0, right_edge = px0 + ITXP >= m1;
     const int iL = m1 - 1 - px0;
-    double* ybw = yb + w * YWAVE;  // this wave's four rows of [xlow 68 | xhigh 68] (yrow_off)
-    const int J = 2 * w;           // first of this wave's two local y-pairs
+    double* ybw = yb + w * YWAVE;  // this wave's RW rows of [xlow HX | xhigh HX] (yrow_off)
+    const int J = YPW * w;         // first of this wave's local y-pairs
 
-    // x stage on the wave's four staged rows (scaled by the y stage): patch mirrored halo columns, rebuild, store
+    // x stage on the wave's RW staged rows (scaled by the y stage): patch mirrored halo columns, rebuild, store
     auto xstage = [&](int zplane, int yrow0) {
-        if ((left_edge | right_edge) && lane < 8) {
+        if ((left_edge | right_edge) && lane < 2 * RW) {
             double* r = ybw + yrow_off(lane >> 1);
             if (left_edge) {
                 if (lane & 1) { r[0] = r[4]; r[1] = r[3]; }              // s[-2] = s[2], s[-1] = s[1]
@@ -562,8 +595,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                 else { r[HX + iL + 3] = r[HX + iL + 1]; r[HX + iL + 4] = r[HX + iL]; }     // d[m] = d[m-2], d[m+1] = d[m-3]
             }
         }
-        // four adjacent x-pairs per lane: lane = 4 * (lane column) + row
-        const int r = lane & 3, i = (lane >> 2) * 4;
+        // four adjacent x-pairs per lane: lane = RW * (lane column) + row
+        const int r = lane % RW, i = (lane / RW) * 4;
         const double* row = ybw + yrow_off(r);
         // local column of pair k is k + 2:  s[i-1..i+5] -> i+1..i+7,  d[i-2..i+5] -> i..i+7
         const double2* ps = reinterpret_cast<const double2*>(row + i);
@@ -580,17 +613,21 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         double* o = ybw + yrow_off(r) + 2 * i;
 #pragma unroll
         for (int k = 0; k < 4; k++) *reinterpret_cast<double2*>(o + 2 * k) = make_double2(ev[k], od[k]);
-        const bool own = px0 + lane < m1;
-        double* dstp = out + (size_t)zplane * o_sz + (size_t)yrow0 * o_sy + 2 * (px0 + lane);
+        // (a store instruction takes 64 / ITXP whole rows of the tile: 1 KB, or two pieces of 512 bytes)
+        constexpr int RPS = 64 / ITXP;
+        const int srow = lane / ITXP, spair = lane % ITXP;
+        const bool own = px0 + spair < m1;
+        double* dstp = out + (size_t)zplane * o_sz + (size_t)(yrow0 + srow) * o_sy + 2 * (px0 + spair);
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const double2 v = *reinterpret_cast<const double2*>(ybw + yrow_off(rr) + 2 * lane);
-            if (own && yrow0 + rr < n2) *reinterpret_cast<double2*>(dstp + (size_t)rr * o_sy) = v;
+        for (int st = 0; st < RW / RPS; st++) {
+            const int rr = st * RPS + srow;
+            const double2 v = *reinterpret_cast<const double2*>(ybw + yrow_off(rr) + 2 * spair);
+            if (own && yrow0 + rr < n2) *reinterpret_cast<double2*>(dstp + (size_t)(st * RPS) * o_sy) = v;
         }
     };
     // y pass of one coefficient column cid of the z-plane in zbuf (scaled by the z step): the wave's four output rows,
     // scaled for the x pass
-    auto ycolumn = [&](const double2* zbuf, int cid, double o[4]) {
+    auto ycolumn = [&](const double2* zbuf, int cid, int J, double (&o)[4]) {  // J: first of the two local y-pairs rebuilt
         const int xh = cid >= HX;             // 0: x-low column, 1: x-high column
         const int col = cid - xh * HX;
         const double* zl = reinterpret_cast<const double*>(zbuf) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
@@ -604,22 +641,27 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 #pragma unroll
         for (int r = 0; r < 4; r++) o[r] *= sc;
     };
-    // The 136 columns are two full passes of the wave and YT = 8 columns more: those of BOTH planes of the z-pair share
-    // one pass (lanes 0..7 the even plane, 8..15 the odd one), five passes per z-pair instead of six.
-    constexpr int YT = 2 * HX - 128;
-    static_assert(YT > 0 && (YT & (YT - 1)) == 0 && 2 * YT <= 64, "y stage: the leftover columns of two planes fit one pass");
+    // The 2 HX columns (136) are NP full passes of the wave (two) and YT = 8 columns more: those of BOTH planes of the z-pair
+    // (and of all the wave's groups of y-pairs) share one pass -- lanes 0..7 the even plane, 8..15 the odd one: five passes
+    // per z-pair and group instead of six.
+    constexpr int NP = (2 * HX) / 64, YT = 2 * HX - 64 * NP;
+    static_assert(YT > 0 && (YT & (YT - 1)) == 0 && 2 * YG * YT <= 64, "y stage: the leftover columns of two planes fit one pass");
+    const int tail_plane = lane / (YG * YT), tail_g = (lane / YT) % YG;  // (lanes below 2 YG YT)
     // y + x stages of the z-plane held in zbuf; tail: this lane's leftover column (mine: of this plane)
-    auto yxstage = [&](int zplane, const double2* zbuf, const double tail[4], bool mine) {
+    auto yxstage = [&](int zplane, const double2* zbuf, const double (&tail)[4], bool mine) {
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            double o[4];
-            ycolumn(zbuf, lane + 64 * p, o);
+        for (int g = 0; g < YG; g++) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) ybw[yrow_off(r) + lane + 64 * p] = o[r];
+            for (int p = 0; p < NP; p++) {
+                double o[4];
+                ycolumn(zbuf, lane + 64 * p, J + 2 * g, o);
+#pragma unroll
+                for (int r = 0; r < 4; r++) ybw[yrow_off(4 * g + r) + lane + 64 * p] = o[r];
+            }
         }
         if (mine) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) ybw[yrow_off(r) + 128 + (lane & (YT - 1))] = tail[r];
+            for (int r = 0; r < 4; r++) ybw[yrow_off(4 * tail_g + r) + 64 * NP + (lane & (YT - 1))] = tail[r];
         }
         xstage(zplane, 2 * (py0 + J));
     };
@@ -675,9 +717,9 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         STAMP(6);
         if (emit) {
             double tail[4] = {0.0, 0.0, 0.0, 0.0};
-            if (lane < 2 * YT) ycolumn(zb + (lane >= YT ? NCI : 0), 128 + (lane & (YT - 1)), tail);
-            yxstage(2 * j, zb, tail, lane < YT);
-            yxstage(2 * j + 1, zb + NCI, tail, lane >= YT && lane < 2 * YT);
+            if (lane < 2 * YG * YT) ycolumn(zb + (tail_plane ? NCI : 0), 64 * NP + (lane & (YT - 1)), J + 2 * tail_g, tail);
+            yxstage(2 * j, zb, tail, lane < YG * YT);
+            yxstage(2 * j + 1, zb + NCI, tail, lane >= YG * YT && lane < 2 * YG * YT);
             STAMP(4);
         }
     }
@@ -740,7 +782,7 @@ static int pick_zps(int tiles, int m3, int per_round)
 
 #ifdef WR_STAMP
 // diagnostic build only: phase stamps of the level-0 launch land here (8 x u64 per wave)
-extern "C" unsigned long long* wr_stamp_buffer(size_t nwaves)
+extern "C" __attribute__((visibility("default"))) unsigned long long* wr_stamp_buffer(size_t nwaves)
 {
     if (!g_stamp_buf) { (void)hipMalloc(&g_stamp_buf, nwaves * 8 * sizeof(unsigned long long)); (void)hipMemset(g_stamp_buf, 0, nwaves * 64); }
     return g_stamp_buf;
@@ -908,7 +950,7 @@ void transform_inv_fused(double* src, double* dst, double* lowbuf, int nx, int n
         size_t o_sy, o_sz;
         if (l == 0) { o = dst; o_sy = f_sy; o_sz = f_sz; }
         else { o = cbuf[l]; o_sy = (size_t)n1; o_sz = (size_t)n1 * n2; }
-        const int tiles = ((m1 + TXP - 1) / TXP) * ((m2 + ITYP - 1) / ITYP);
+        const int tiles = ((m1 + ITXP - 1) / ITXP) * ((m2 + ITYP - 1) / ITYP);
         const int zps = pick_zps(tiles, m3, 256 * (int)(160 * 1024 / LDS_INV));
         dim3 grid(tiles, (m3 + zps - 1) / zps);
 #ifdef WR_STAMP

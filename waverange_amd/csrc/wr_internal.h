@@ -116,7 +116,7 @@ struct DevPlanes {
     // smallest idle buffer that holds `bytes` without being more than twice as large, else a new one; {nullptr, 0} if the
     // device (or the cap) has no room right now.  The cap is checked and the bytes are booked in ONE critical section, so
     // callers that arrive together cannot all pass the check and overshoot it.
-    Buf take(size_t bytes);
+    Buf take(size_t bytes, size_t held_by_caller = 0);
     void give(const Buf& b)
     {
         { std::lock_guard<std::mutex> lk(mu); idle.push_back(b); }

@@ -126,7 +126,7 @@ void* DevPlanes::device_alloc(size_t bytes, bool others_hold_planes)
     return q;
 }
 
-DevPlanes::Buf DevPlanes::take(size_t bytes)
+DevPlanes::Buf DevPlanes::take(size_t bytes, size_t held_by_caller)
 {
     for (int attempt = 0; attempt < 2; attempt++) {
         bool any_idle = false, booked = false, others = false;
@@ -138,7 +138,7 @@ DevPlanes::Buf DevPlanes::take(size_t bytes)
             if (best >= 0) { Buf b = idle[best]; idle[best] = idle.back(); idle.pop_back(); return b; }
             any_idle = !idle.empty();
             if (!chunk_limit || allocated + bytes <= chunk_limit) {
-                others = allocated > 0;  // planes in use by any call (this one's earlier chunks included: they drain too) or idle ones
+                others = allocated > held_by_caller;  // planes of OTHER calls (in use or idle): something that can come back
                 allocated += bytes;
                 wri::g_stat[WR_STAT_DEVICE_PLANE_BYTES] += bytes;
                 booked = true;
@@ -395,7 +395,15 @@ DevPlanes::Buf plane_buffer_wait(wr_ctx* c, size_t bytes, std::unique_lock<std::
     const double t0 = now();
     bool waited = false;
     for (;;) {
-        const DevPlanes::Buf b = dp.take(bytes);  // (the cap is checked and booked there, idle buffers of other sizes make room)
+        // (the cap is checked and booked there, idle buffers of other sizes make room; what this context holds itself does not
+        // count as "somebody can give memory back": the reserve never makes a lone caller wait for its own planes)
+        size_t mine = 0;
+        for (int l = 0; l < WR_NLAYMAX; l++) {
+            const PlaneStream& s = c->ps[l];
+            if (!s.chunks.empty()) { for (const DevPlanes::Buf& q : s.chunks) if (q.p) mine += q.bytes; }
+            else if (s.dev) mine += s.dev_bytes;
+        }
+        const DevPlanes::Buf b = dp.take(bytes, mine);
         if (b.p) { if (waited) g_stat[WR_STAT_PLANE_WAIT_MS] += (unsigned long)((now() - t0) * 1e3); return b; }
         if (!waited) {
             // what this call has queued must not straddle the gap in its kernel stage

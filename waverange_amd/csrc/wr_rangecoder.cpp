@@ -26,6 +26,21 @@
 
 namespace wrrc {
 
+#ifdef WR_PROBE_HDR
+// tools/native/hdr_probe.cpp: cycles the 16-lane sessions spend in the block headers (scalar, 257 coder steps per block and
+// stream) against the cycles of whole steps
+unsigned long long g_probe_hdr[4];  // encoder headers, encoder steps, decoder headers, decoder steps
+struct ProbeScope {
+    const int i;
+    const unsigned long long t0 = __builtin_ia32_rdtsc();
+    explicit ProbeScope(int k) : i(k) {}
+    ~ProbeScope() { g_probe_hdr[i] += __builtin_ia32_rdtsc() - t0; }
+};
+#define WR_PROBE(i) ProbeScope probe_scope_##i(i)
+#else
+#define WR_PROBE(i) do { } while (0)
+#endif
+
 // CPU dispatch for the AVX-512 loops.  Lives here, not next to them: wr_rangecoder_avx512.cpp is built with
 // -mavx512*, so the compiler may use those instructions anywhere in that file -- also in a function whose job is to
 // find out whether the CPU has them.
@@ -515,6 +530,7 @@ public:
     void step(OnEnd on_end)
     {
         if (count_ <= kMaxEncStreams) { EncGroup::step_streams(count_, es_, store_, st_, tabs_, tops_, on_end); return; }
+        WR_PROBE(1);
         uint32_t bs[kCap];
         VecEncBlock vb;
         vb.active = 0;
@@ -528,7 +544,9 @@ public:
             const size_t left = s.n - s.done;
             bs[k] = left < kBlock ? (uint32_t)left : kBlock;
             ss[k] = s.sym.at(s.done, s.n);
-            if ((!ss[k] && bs[k]) || !encode_block_header(*es_[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k])) {
+            bool header_ok;
+            { WR_PROBE(0); header_ok = !(!ss[k] && bs[k]) && encode_block_header(*es_[k], ss[k], bs[k], s.hist ? s.hist + s.blk * 256 : nullptr, tabs_[k], &tops_[k]); }
+            if (!header_ok) {
                 s.failed = true; bs[k] = 0;
                 continue;
             }
@@ -1355,6 +1373,7 @@ public:
     template <class OnEnd>
     void step(OnEnd on_end)
     {
+        WR_PROBE(3);
         VecBlock vb;
         if (!prepare(on_end, vb)) return;
         if (vb.active) vec_decode_block(&vb, vec_other_symbol);
@@ -1374,6 +1393,8 @@ public:
             Dec& d = *ds_[k];
             BlockModel& m = *ms_[k];
             bool ended = false;
+            {
+            WR_PROBE(2);
             if (!d.culfreq(2)) { d.renorm(); ended = true; }
             else {
                 d.update(1, 1, 2);
@@ -1390,6 +1411,7 @@ public:
                     m.top = top_sym; m.bs = bs;
                     finish_model_stats(m);
                 }
+            }
             }
             if (ended) { retire(k, on_end); continue; }
             const size_t at = produced_[k] < n_[k] ? produced_[k] : n_[k];
