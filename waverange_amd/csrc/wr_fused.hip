@@ -524,6 +524,12 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
 #ifdef WR_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
+#if defined(WR_INV_MEMONLY) && defined(WR_INV_MEMPITCH)
+    // DIAGNOSTIC: the detail octants read with a row pitch that is not a power of two (what a padded coefficient array
+    // would give); planes wrap so that the padded strides stay inside the array
+    const int pad_planes = (int)(((size_t)n1 * n2 * n3) / ((size_t)WR_INV_MEMPITCH * n2)) - 1;
+    s_sy = WR_INV_MEMPITCH; s_sz = (size_t)WR_INV_MEMPITCH * n2;
+#endif
     extern __shared__ double2 lds2[];
     double2* zb = lds2;                   // [2][NCI]   the two z-reconstructed planes of a step
     double* yb = reinterpret_cast<double*>(lds2 + 2 * NCI);  // [INWAVE][YWAVE] wave-private rows
@@ -559,14 +565,31 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         offH[k] = so;
         offL[k] = (q == 0) ? (int)(gyp * l_sy) + gxp : so;
         if (q == 0) lll_mask |= 1u << k;
+#if defined(WR_INV_MEMONLY) && defined(WR_INV_MEMPAT)
+        // DIAGNOSTIC: the same number of loads, but every wave's load instruction takes 1 KB of consecutive, aligned bytes from
+        // a 32 KB region of the plane that belongs to this tile alone (what a tile-blocked coefficient layout with the halo
+        // stored twice would give): the price of the row-segment shape of the real pattern is the difference
+        {
+            const int tile_lin = blockIdx.x % ((int)((size_t)n1 * n2 / 4096) > 0 ? (int)((size_t)n1 * n2 / 4096) : 1);
+            const int lin = (c % (NCI / 2 < 2048 ? NCI / 2 : 2048)) * 2;
+            offH[k] = tile_lin * 4096 + lin;
+            offL[k] = offH[k];
+            lll_mask = 0;
+        }
+#endif
     }
     // the coefficient chunks of z-pair t go straight into registers: the z step is the only reader,
     // it runs first in a step, and the registers are free again for the next pair right after it.
     double2 rl[KCI], rh[KCI];
     auto fetch = [&](int t) {
         const double* pll = low + (size_t)t * l_sz;
+#if defined(WR_INV_MEMONLY) && defined(WR_INV_MEMPITCH)
+        const double* pl = src + (size_t)(t % pad_planes) * s_sz;
+        const double* ph = src + (size_t)((m3 + t) % pad_planes) * s_sz;
+#else
         const double* pl = src + (size_t)t * s_sz;
         const double* ph = src + (size_t)(m3 + t) * s_sz;
+#endif
         // (non-temporal loads: 5.10 against 4.15 ms -- the halo lines a neighbour tile fetches again then come from HBM; all
         // low-z chunks before all high-z ones, non-temporal stores: within 1 %: profiles/r05/c_ab_inverse_nontemporal_*.txt)
 #pragma unroll
@@ -681,6 +704,36 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         // it is the last / the first pair), pair t-2 leaves (last2: it is the last pair)
         const bool first = t == 0, last1 = t - 1 >= m3 - 1, first1 = t - 1 <= 0, last2 = j >= m3 - 1;
         STAMP(7);
+#ifdef WR_INV_MEMONLY
+        // DIAGNOSTIC (not a transform): the kernel's loads and stores alone -- same addresses, same instructions, same order,
+        // WR_INV_MEMONLY=2 also the two barriers -- with one addition per loaded value in place of the three lifting passes
+        // and no LDS traffic: what the access pattern costs by itself.
+        {
+            if (WR_INV_MEMONLY == 2) lds_barrier();
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < KCI; k++)
+                if ((valid_mask >> k) & 1) acc += (rl[k].x + rl[k].y) + (rh[k].x + rh[k].y);
+            if (t + 1 <= te && t + 1 < m3) fetch(t + 1);
+            if (WR_INV_MEMONLY == 2) lds_barrier();
+            if (emit) {
+                constexpr int RPS = 64 / ITXP;
+                const int srow = lane / ITXP, spair = lane % ITXP;
+                const bool own = px0 + spair < m1;
+#pragma unroll
+                for (int pl2 = 0; pl2 < 2; pl2++) {
+                    const int yrow0 = 2 * (py0 + J);
+                    double* dstp = out + (size_t)(2 * j + pl2) * o_sz + (size_t)(yrow0 + srow) * o_sy + 2 * (px0 + spair);
+#pragma unroll
+                    for (int st = 0; st < RW / RPS; st++) {
+                        const int rr = st * RPS + srow;
+                        if (own && yrow0 + rr < n2) *reinterpret_cast<double2*>(dstp + (size_t)(st * RPS) * o_sy) = make_double2(acc, acc + pl2);
+                    }
+                }
+            }
+            continue;
+        }
+#endif
         lds_barrier();  // the previous step's readers of zb are done
         STAMP(1);
         // ---- z step on every staged point  (waveletcdf97_3d.c:312-337 along z)
