@@ -564,6 +564,8 @@ def main():
     ap.add_argument("--pool", type=int, default=-1, help="coder-pool worker threads shared by all fields in flight (-1: one per CPU of this rank; 0: no pool, "
                     "every call runs its own --threads coder threads)")
     ap.add_argument("--dec-streams", type=int, default=4, help="plane streams a pool worker's decoder loop interleaves (1..4)")
+    ap.add_argument("--no-warm-transforms", action="store_true", help="skip the back-to-back transforms behind the timed region (roofline_warm): a profiled run "
+                    "then holds only the pipeline's launches of k_inv_fused (tools/final_profiles.sh)")
     ap.add_argument("--secondary-steps", type=int, default=2, help="steps of the secondary pass at --secondary-tol after the timed region (N = 1 only; 0: none)")
     ap.add_argument("--secondary-tol", type=float, default=1e-16, help="BASELINE configs[4]'s near-lossless tolerance: 8 planes per field, mostly noise")
     ap.add_argument("--secondary-lanes", type=int, default=8, help="fields in flight in the secondary pass (each holds up to 2 x 6 GB of coded bytes at 1024^3)")
@@ -1085,6 +1087,8 @@ def main():
         # the same transform kernels back to back on a busy GPU (outside the timed region): what they do with the
         # shader clock up -- inside the pipeline every kernel stage starts on a GPU that has been idle
         try:
+            if args.no_warm_transforms:
+                raise RuntimeError("skipped (--no-warm-transforms)")
             wbuf = ctx.alloc(nelem * 8)
             ctx.synth_field(wbuf, n, n, n, 12345 + rank)
             ctx.sync()

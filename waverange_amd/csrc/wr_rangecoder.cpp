@@ -386,7 +386,7 @@ struct SymCursor {
         return base + (pos - first);
     }
     size_t room(size_t pos) const { return pos < first + count ? first + count - pos : 0; }  // symbols from pos on that exist here
-    void end(size_t pos) { if (io) { size_t z = 0; (void)io->window(io->user, pos, &z); } }
+    void end(size_t pos) { if (io && !refused) { size_t z = 0; (void)io->window(io->user, pos, &z); } }  // (a refused stream has nothing to end)
 };
 }  // namespace
 
