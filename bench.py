@@ -709,6 +709,9 @@ def main():
     trim_host = bool(limits.get("host_pages_of_consumed_streams_dropped")) or args.trim_host
     pool_workers = max(1, int(limits["cpus_per_rank"])) if args.pool < 0 else args.pool
     if pool_workers:
+        # (every worker pinned to a physical core of its own -- the idlest of the box, the GPU's NUMA node first -- was measured:
+        # 14.87 / 14.81 against 14.93 / 14.83 GB/s, same box, K = 8: profiles/r05/h_ab_pool_workers_pinned_k8_same_box.txt.  Where the
+        # scheduler puts the workers is not what makes the boxes differ.)
         api.set_coder_pool(pool_workers, args.dec_streams)
 
     # One lane per field of the batch (jobs x tolerance settings: independent jobs that run concurrently on

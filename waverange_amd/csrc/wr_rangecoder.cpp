@@ -12,6 +12,8 @@
 #include "wr_rangecoder_vec.h"
 
 #include <math.h>
+#include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1806,6 +1808,11 @@ private:
 
     void run(int id)
     {
+        {   // the workers carry a name (wr-coder-<id>): a caller that places threads on cores finds them in /proc/self/task
+            char name[16];
+            snprintf(name, sizeof name, "wr-coder-%d", id);
+            (void)pthread_setname_np(pthread_self(), name);
+        }
         int dec_streams;
         { std::lock_guard<std::mutex> lk(mu_); dec_streams = dec_streams_; }
         std::unique_ptr<DecGroup> dg;
