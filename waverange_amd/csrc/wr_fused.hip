@@ -314,6 +314,17 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             STAMP(0);
             __syncthreads();                      // ... and everybody else's
             STAMP(1);
+#ifdef WR_FWD_MEMONLY
+            // DIAGNOSTIC (not a transform): the kernel's loads (LDS-DMA) and stores alone, with its barriers; the x and y lifting
+            // and their LDS traffic are gone, the z step works on constants
+            lds_barrier();
+            if (more) fetch(t + 1, 0);
+            lds_barrier();
+            lds_barrier();
+            if (more) fetch(t + 1, 1);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { a[q] = 1.0 + q; b[q] = 2.0 + t; }
+#else
             xlift(0);
             STAMP(2);
             lds_barrier();
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(NTHR, 2) void k_fwd_fused(
             STAMP(3);
             ylift(b);
             STAMP(4);
+#endif
         }
         // ---- z step: (a, b) is z-pair t  (waveletcdf97_3d.c:228-262).  Pair t-1 gets its first half
         // (last1 / first1: it is the last / first pair), pair t-2 its second half and leaves.
