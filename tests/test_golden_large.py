@@ -97,6 +97,14 @@ def test_every_rank_of_config4_has_a_pin():
         assert rec["seed"] == SEED + r and rec["n"] == 512 and rec["nlay"] == 4
         shas.add(rec["input_sha256"])
     assert len(shas) == 8
+    # ... and of a weak-scaling bench.py run at 1024^3 (every rank round-trips its own field at tol 1e-3 and 1e-7)
+    shas = set()
+    for r in range(8):
+        for tol, nlay in ((1e-3, 3), (1e-7, 4)):
+            rec = g[key(1024, tol, SEED + r)]
+            assert rec["seed"] == SEED + r and rec["n"] == 1024 and rec["nlay"] == nlay, (r, tol)
+        shas.add(g[key(1024, 1e-3, SEED + r)]["input_sha256"])
+    assert len(shas) == 8
 
 
 @pytest.mark.skipif(not os.environ.get("WR_GOLDEN_1024"), reason="ten minutes of CPU and 40 GiB: WR_GOLDEN_1024=1 (log of a run: profiles/r03/oracle_vs_reference_pins_1024.log)")
