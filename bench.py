@@ -4,8 +4,8 @@ host buffer (BASELINE.json metric: "encode+decode MB/s per GPU on 1024^3 fp64; %
 tol"; SURVEY.md 8d(1): the reference API takes and returns host arrays).
 
 One step = one batch of fields per GPU (default 6 per tolerance setting = 12), K steps = K batches.  The fields of a
-run are pulled from one queue by jobs x len(tols) lanes (default 12 x 2: 1.5 fields in flight per CPU of the rank, fewer
-if its CPUs, host memory or HBM are short), so up to 24 fields are in flight and steps overlap; a lane is an encoder
+run are pulled from one queue by jobs x len(tols) lanes (default 20 x 2: 2.5 fields in flight per CPU of the rank, fewer
+if its CPUs, host memory or HBM are short), so up to 40 fields are in flight and steps overlap; a lane is an encoder
 context and a decoder context with two coded-stream buffers between them: it encodes its next field while it decodes
 the previous one.  Every field starts in a pinned host buffer and is encoded (upload; min/max, forward CDF-9/7,
 bit-plane quantizer on the GPU, the planes staying in HBM; rngcod13 range coder on the host, which pulls the planes
@@ -322,7 +322,7 @@ class SizingRefused(SystemExit):
 
 
 def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=True, pooled=False, out_pool=4, gpus_on_node=1, nslots=3, planes_per_field=4,
-             fields_per_cpu=2.0, host_mem=None, cpus=None, local_world=None):
+             fields_per_cpu=2.5, host_mem=None, cpus=None, local_world=None, hbm_per_lane=0.6):
     """Largest jobs <= want whose lanes (jobs x ntols) fit this rank's share of the host CPUs, the host
     memory and the free HBM.  Returns (jobs, {what was found}).  Host memory decides in three steps (a rank never allocates
     what its share cannot hold: an 8-GPU node with little memory per GPU must not turn its first run into an OOM kill):
@@ -399,7 +399,7 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # (planes_per_field: 1 byte per element and plane, encoder and decoder context of a lane each hold a field's planes)
     # an encoder's planes drain as its coder advances (half of them are gone on average), a decoder's stay until its field is
     # done: 0.75 of the two contexts' worst case; a call that finds no room for a plane waits for chunks to come back
-    by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((0.75 * planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
+    by_hbm = int((0.92 * hbm_free - nslots * 2.2 * field_bytes) // ((hbm_per_lane * planes_per_field / 4.0 if host_mode else 3.0) * field_bytes * ntols))
     if by_hbm < 1:
         raise SizingRefused("bench.py: %.1f GiB of free HBM cannot hold %d work-space slots (2.2 x %.1f GiB each) and one lane per tolerance"
                             % (hbm_free / 2 ** 30, nslots, field_bytes / 2 ** 30))
@@ -552,8 +552,10 @@ def main():
     ap.add_argument("--tols", type=str, default="1e-3,1e-7")
     ap.add_argument("--cpu-size", type=int, default=448)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jobs", type=int, default=16, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
-    ap.add_argument("--fields-per-cpu", type=float, default=2.0, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
+    ap.add_argument("--jobs", type=int, default=20, help="fields in flight per tolerance (lanes = jobs x tols); cut down to what the rank's CPUs, host memory and HBM allow")
+    ap.add_argument("--fields-per-cpu", type=float, default=2.5, help="fields in flight per CPU of the rank that the coder pool is given (the upper bound the CPUs put on --jobs)")
+    ap.add_argument("--hbm-per-lane", type=float, default=0.6, help="plane memory a lane is budgeted in HBM, in field sizes at four planes per field (measured: 40 lanes "
+                    "hold 194-196 GiB of planes at 1024^3 since decodes wait for admission to the coder pool WITHOUT their planes: 0.61)")
     ap.add_argument("--trim-host", action="store_true", help="hand the pages of consumed coded streams back to the system (done by itself when host memory is what limits the lanes)")
     ap.add_argument("--timeline", type=str, default=None, help="write what the coder pool did every half second of the timed region to this file (fill and drain of a run)")
     ap.add_argument("--out-buffers", type=int, default=4, help="pinned output fields shared by all lanes (host mode: a decode needs one only for its last ~0.25 s)")
@@ -684,7 +686,7 @@ def main():
     # non-zero status and the arithmetic on stderr before it has allocated anything; under a launcher the other ranks follow)
     n, jobs, limits = fit_jobs_or_smaller(n, args.jobs, len(tols), n ** 3 * 8, torch.cuda.mem_get_info(dev_index)[0], share, host_mode,
                                           pooled=args.pool != 0, out_pool=args.out_buffers, gpus_on_node=gpus_on_node, nslots=args.slots or 3,
-                                          planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu)
+                                          planes_per_field=8 if min(tols) < 1e-12 else 4, fields_per_cpu=args.fields_per_cpu, hbm_per_lane=args.hbm_per_lane)
     if limits.get("fell_back_from_size") and rank == 0:
         print("bench.py: --size %d does not fit this rank's host memory, running --size %d instead: %s"
               % (limits["fell_back_from_size"], n, limits["refusal_at_that_size"]), file=sys.stderr)
@@ -921,6 +923,7 @@ def main():
     cpu0 = sum(os.times()[:2])
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
     burn0 = api.stat(api.STAT_CLOCK_WARMUP_MS)
+    gate0 = api.stat(api.STAT_DECODE_GATE_MS)
     queue0, pwait0 = api.stat(api.STAT_POOL_QUEUE_MS), api.stat(api.STAT_PLANE_WAIT_MS)
     loops0 = api.pool_loop_stats()
     sampler = stop_sampling = None
@@ -954,6 +957,7 @@ def main():
     nfields = max(1, args.steps * batch)
     queue_wait = (api.stat(api.STAT_POOL_QUEUE_MS) - queue0) * 1e-3 / nfields   # per field: its planes' waits for a pool worker, summed
     plane_wait = (api.stat(api.STAT_PLANE_WAIT_MS) - pwait0) * 1e-3 / nfields   # per field: waits for device memory for its planes
+    gate_wait = (api.stat(api.STAT_DECODE_GATE_MS) - gate0) * 1e-3 / nfields     # per field: a decode's wait for admission to the pool (no planes held yet)
     burn_ms = (api.stat(api.STAT_CLOCK_WARMUP_MS) - burn0) / float(nfields)     # per field: clock warm-up load in front of its two kernel stages (0 unless WR_CLOCK_WARMUP_MS)
     loops1 = api.pool_loop_stats()
     pool_loops = {}
@@ -1117,7 +1121,8 @@ def main():
         out["hbm_planes_gib"] = round(api.stat(api.STAT_DEVICE_PLANE_BYTES) / 2 ** 30, 1)  # device buffers of quantized planes (in use + idle)
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
         out["pool_loops"] = pool_loops
-        out["waits_per_field_s"] = {"planes_in_the_pool_queue_summed": round(queue_wait, 2), "device_memory_for_planes": round(plane_wait, 2)}
+        out["waits_per_field_s"] = {"planes_in_the_pool_queue_summed": round(queue_wait, 2), "device_memory_for_planes": round(plane_wait, 2),
+                                    "decode_admission_gate": round(gate_wait, 2)}
         out["pool_workers_idle"] = round(pool_idle, 2)  # of the pool's workers, how many were waiting for a job on average
         if throttled is not None:
             out["cpu_quota_throttled"] = round(throttled, 3)  # cgroup cpu.stat throttled time / wall time of the timed region

@@ -188,6 +188,8 @@ int wr_set_device_slots(int device, int nslots);
                                       call concerned fails) */
 #define WR_STAT_CLOCK_WARMUP_MS 8  /* milliseconds of clock warm-up load put in front of kernel stages (WR_CLOCK_WARMUP_MS, a measurement
                                       hook that is off by default: always 0 then) */
+#define WR_STAT_DECODE_GATE_MS 9   /* milliseconds decode calls have waited for admission to the coder pool, holding no device memory yet
+                                      (before: the same time in the pool's queues with their planes allocated), summed over calls */
 unsigned long wr_stat(int what);
 /* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder}
  * -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block steps of that loop and stream-blocks (60000

@@ -336,6 +336,46 @@ def test_coder_pool_codes_all_fields_in_flight(api, oracle):
     assert not errors, errors
 
 
+def test_decodes_wait_for_admission_without_their_planes(api, oracle):
+    """A pooled decode whose kind's queues are long waits at the pool's admission gate BEFORE it prepares its planes (decode_impl:
+    a third of the decoders' plane memory used to be held by planes that sat in the queues, and plane memory bounds the fields
+    in flight): twelve concurrent decodes of an eight-plane field on a pool of two workers -- the gate is taken
+    (WR_STAT_DECODE_GATE_MS moves), every reconstruction is the oracle's, and nothing is left behind."""
+    f = synth.field(128, 96, 80, seed=21)
+    e = oracle.encode(f, 1e-16)
+    rec = oracle.decode(e, f.shape)
+    e = {k: v for k, v in e.items() if k != "residual"}
+    api.set_coder_pool(2, 4)
+    gate0, refused0 = api.stat(api.STAT_DECODE_GATE_MS), api.stat(api.STAT_HANDOVER_ERRORS)
+    errors = []
+
+    def worker(k):
+        try:
+            with api.Context(0) as c:
+                for rep in range(2):
+                    out = np.empty_like(f)
+                    if (k + rep) % 2:
+                        c.decode_begin(f.shape, e)
+                        c.decode_finish_host(out)
+                    else:
+                        c.decode_host(out, e)
+                    assert bits_equal(out, rec), (k, rep)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((k, exc))
+
+    try:
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        api.set_coder_pool(0)
+    assert not errors, errors
+    assert api.stat(api.STAT_DECODE_GATE_MS) > gate0, "no decode ever waited at the gate: 96 plane jobs on two workers"
+    assert api.stat(api.STAT_HANDOVER_ERRORS) == refused0
+
+
 def test_two_phase_decode(ctx, api, oracle):
     """wr_decode_begin (host range decoding, no field buffer) + wr_decode_finish_host / _device (upload, kernels,
     download): same reconstruction as the one-call decode, with per-call coder threads and with the pool; the

@@ -65,16 +65,16 @@ def test_bench_batch_sizing():
     with pytest.raises(bench.SizingRefused):
         bench.fit_jobs(5, 2, fb, 40 * 10 ** 9, host_mode=False, host_mem=big)
     # host buffer to host buffer (the default): the planes of the fields in flight live in HBM -- a decoder's until its field is
-    # done, an encoder's draining chunk by chunk: 0.75 of the two contexts' worst case per lane -- the host holds their coded
-    # streams
+    # done (and only from the moment it is admitted to the coder pool), an encoder's draining chunk by chunk: 0.6 of the two
+    # contexts' worst case per lane (--hbm-per-lane) -- the host holds their coded streams
     jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, host_mem=big)
-    assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (0.75 * fb * 2)) and jobs <= max(1, lim["jobs_by_host_mem"])
+    assert lim["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (0.6 * fb * 2)) and jobs <= max(1, lim["jobs_by_host_mem"])
     # two slots leave room for more lanes; tol 1e-16 (8 planes per field) for half as many
-    assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, nslots=2, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 2 * 2.2 * fb) // (0.75 * fb * 2))
-    assert bench.fit_jobs(64, 1, fb, 288 * 10 ** 9, planes_per_field=8, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (1.5 * fb))
-    # with the coder pool a lane is not a thread: two fields in flight per CPU (--fields-per-cpu)
+    assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, nslots=2, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 2 * 2.2 * fb) // (0.6 * fb * 2))
+    assert bench.fit_jobs(64, 1, fb, 288 * 10 ** 9, planes_per_field=8, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (1.2 * fb))
+    # with the coder pool a lane is not a thread: two and a half fields in flight per CPU (--fields-per-cpu)
     jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True, host_mem=big)
-    assert lim["jobs_by_cpu"] == max(1, int(2.0 * lim["cpus_per_rank"] // 2))
+    assert lim["jobs_by_cpu"] == max(1, int(2.5 * lim["cpus_per_rank"] // 2))
     assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True, fields_per_cpu=1.5, host_mem=big)[1]["jobs_by_cpu"] == max(1, int(1.5 * lim["cpus_per_rank"] // 2))
     # where host memory is what holds the lanes back, consumed coded streams hand their pages back and more lanes fit
     plenty, tight = 2048 * 2 ** 30, 120 * 2 ** 30

@@ -572,6 +572,8 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
 // buffer: no field buffer and no slot needed, wr_decode_begin); or only its device half on planes decoded before
 // (wr_decode_finish_*)
 enum DecodeMode { kDecodeWhole, kDecodeBegin, kDecodeFinish };
+// admission gate of the pooled decoder (decode_impl): queued jobs of a kind at which a further decode waits
+constexpr int kGateScalarJobs = 3, kGateVectorJobs = 6;
 
 int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_info* info, const unsigned char* data_enc,
                 size_t data_len, wr_timings* tm, DecodeMode mode = kDecodeWhole)
@@ -616,6 +618,25 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
     if (off[nlay] > info->ntot_enc) return fail(WR_ERR_STREAM, "len_enc_vec exceeds ntot_enc");
     if (host_half && data_len && info->ntot_enc > data_len) return fail(WR_ERR_STREAM, "ntot_enc exceeds the length of the coded buffer");
 
+    // Admission to the coder pool.  A decoder's planes take device memory from the moment they are prepared, and with every
+    // session of the pool full a decode's jobs sat in the queues for seconds (4 of a decode's 15 s at 32 lanes) -- a third of
+    // the decoders' plane memory was held by planes nobody was writing yet, and plane memory is what bounds the fields in
+    // flight.  So a decode waits HERE, holding nothing, until the queues of its kind are short (a free lane of a session is
+    // refilled at the next block boundary, half a millisecond away: a couple of queued jobs keep every session topped up),
+    // and only then prepares its planes and submits: the same wait, without the memory.  One decode at a time passes, from
+    // the look at the queues to the submit (else all that wait would pass together).
+    std::unique_lock<std::mutex> gate(pool->planes.gate_mu, std::defer_lock);
+    if (host_half && wrrc::pool_threads() > 0) {
+        gate.lock();
+        const double t_gate = now();
+        for (;;) {
+            int qs = 0, qv = 0;
+            wrrc::pool_queued_decode(&qs, &qv);
+            if ((qs < kGateScalarJobs && qv < kGateVectorJobs) || now() - t_gate > 120.0) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        g_stat[WR_STAT_DECODE_GATE_MS] += (unsigned long)((now() - t_gate) * 1e3);
+    }
     if (host_half) {
         c->pend_valid = false;  // whatever an earlier begin parked here is overwritten now
         // one decode at a time gathers its planes: a decoder keeps them all until its field is done, so two that each hold
@@ -650,12 +671,15 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
                 jobs[l].kind = wrrc::PlaneJob::kDecode;
                 jobs[l].src = data_enc + off[l]; jobs[l].src_len = info->len_enc_vec[l]; jobs[l].dst = nullptr; jobs[l].io = &c->ps[l].io; jobs[l].n = n;
             }
-            if (wrrc::pool_submit(jobs, nlay, &batch)) {
+            const bool queued = wrrc::pool_submit(jobs, nlay, &batch);
+            if (gate.owns_lock()) gate.unlock();  // the next decode may look at the queues now
+            if (queued) {
                 wrrc::pool_wait(&batch);
                 for (int l = 0; l < nlay; l++) { got[l] = jobs[l].result; coder_s[l] = jobs[l].seconds; }
             } else
                 pooled = false;  // the pool was stopped meanwhile: this call's own threads decode the planes
         }
+        if (gate.owns_lock()) gate.unlock();
         const int groups = (pooled || !host_half) ? 0 : std::min(nlay, coder_threads());
         // Every decoded window of a plane goes to the plane's device buffer while the decoder fills the next one
         // (chunk by chunk: wrappers.cpp:492-516 reorganised); the accumulate kernel consumes the

@@ -95,6 +95,7 @@ struct DevPlanes {
     size_t allocated = 0;         // bytes this device's planes hold right now, in use + idle + reserved for an allocation under way (mu)
     std::condition_variable cv;   // a buffer came back (calls waiting for device memory: plane_prepare)
     std::mutex gather_mu;         // held by the one decode that is gathering its planes (wr_codec.cpp)
+    std::mutex gate_mu;           // decodes pass the pool's admission gate one at a time: from the look at the queues to the submit
     size_t chunk_bytes = 0;       // large planes live in chunks of this size or more (WR_PLANE_CHUNK_MB, default 32 MiB; 0: not read yet)
     size_t chunk_limit = 0;       // WR_PLANE_LIMIT_MB: device memory the planes of all calls may take together (0: what the device gives)
     // What the planes leave of the device's memory to everybody else (WR_PLANE_RESERVE_MB, default 2 GiB): the planes are

@@ -1664,6 +1664,7 @@ private:
     }
 public:
     double idle_seconds() { std::lock_guard<std::mutex> lk(mu_); return idle_s_; }
+    void queued_decode(int* scalar_jobs, int* vector_jobs) { std::lock_guard<std::mutex> lk(mu_); *scalar_jobs = (int)dec_q_.size(); *vector_jobs = (int)vec_q_.size(); }
     void set_steal_idle_test(int workers) { std::lock_guard<std::mutex> lk(mu_); steal_idle_test_ = workers < 0 ? 0 : workers; }
     double queue_seconds() { return queued_ns_.load() * 1e-9; }
     unsigned long streams_moved() { return moved_.load(); }
@@ -1903,6 +1904,7 @@ void pool_test_steal_idle_min(int workers) { Pool::get().set_steal_idle_test(wor
 int pool_threads() { return Pool::get().threads(); }
 double pool_idle_seconds() { return Pool::get().idle_seconds(); }
 double pool_queue_seconds() { return Pool::get().queue_seconds(); }
+void pool_queued_decode(int* scalar_jobs, int* vector_jobs) { Pool::get().queued_decode(scalar_jobs, vector_jobs); }
 unsigned long pool_streams_moved() { return Pool::get().streams_moved(); }
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]) { Pool::get().loop_stats(seconds, blocks); }
 bool pool_submit(PlaneJob* jobs, int count, JobBatch* batch) { return Pool::get().submit(jobs, count, batch); }

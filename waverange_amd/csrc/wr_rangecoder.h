@@ -105,6 +105,8 @@ constexpr int kLoopKinds = 4;
 // per loop kind {scalar enc, scalar dec, vector dec (dominant symbols), vector enc}: worker seconds in block steps, stream-blocks advanced
 void pool_loop_stats(double seconds[kLoopKinds], double blocks[kLoopKinds]);
 unsigned long pool_streams_moved();  // streams that changed workers between two blocks (an idle worker took over half of the fullest session)
+// decoder jobs that are queued and no worker has taken yet: {planes for the scalar loops (noise), planes for the 16-lane sessions}
+void pool_queued_decode(int* scalar_jobs, int* vector_jobs);
 double pool_queue_seconds();  // time jobs have waited in the pool's queues before a worker took them, summed over jobs
 double pool_idle_seconds();  // time the workers have spent waiting for a job since the process started, summed over workers
 // The jobs must stay valid until pool_wait returns.  False (nothing queued) if the pool has no workers -- it may have
