@@ -477,6 +477,25 @@ __device__ inline int yrow_off(int r) { return r * YPITCH + (r & 1) * 10; }
 #endif
 constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * YWAVE * 8;
 
+// A double of another lane of the quad (lanes 4q .. 4q + 3), by DPP: `v_mov_b32 ... quad_perm:[..]` on either half.
+// 0xB1 = quad_perm:[1,0,3,2] (the lane one over), 0x4E = quad_perm:[2,3,0,1] (the lane two over).
+template <int CTRL>
+__device__ inline double quad_lane(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// One stage of the 4 x 4 transpose of {a, b} held by the lanes of a quad: the lanes with `odd` set hand their `a` to their
+// partner and take its `b`, the others the other way round.
+template <int CTRL>
+__device__ inline void quad_exchange(bool odd, double& a, double& b)
+{
+    const double got = quad_lane<CTRL>(odd ? a : b);
+    a = odd ? got : a;
+    b = odd ? b : got;
+}
+
 // whole-sample symmetric extension in coefficient space (even length 2M):
 //   low-pass  s[-k] = s[k],    s[M-1+k] = s[M-k]
 //   high-pass d[-k] = d[k-1],  d[M-1+k] = d[M-1-k]
@@ -643,22 +662,42 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         double ev[4], od[4];
         lift_inv_four(sv, dv, ev, od);
         // The lane's eight results are 64 consecutive bytes of its row: stored as they are, every store instruction would
-        // write 16 bytes out of every 64.  They go back to the wave's rows instead (everything has been read: LDS runs a
-        // wave's instructions in order) and leave row by row, one x-pair per lane: 1 KB of consecutive bytes per instruction.
-        double* o = ybw + yrow_off(r) + 2 * i;
-#pragma unroll
-        for (int k = 0; k < 4; k++) *reinterpret_cast<double2*>(o + 2 * k) = make_double2(ev[k], od[k]);
+        // write 16 bytes out of every 64.  They leave row by row instead, one x-pair per lane: 1 KB of consecutive bytes per
+        // instruction.
         // (a store instruction takes 64 / ITXP whole rows of the tile: 1 KB, or two pieces of 512 bytes)
         constexpr int RPS = 64 / ITXP;
         const int srow = lane / ITXP, spair = lane % ITXP;
         const bool own = px0 + spair < m1;
         double* dstp = out + (size_t)zplane * o_sz + (size_t)(yrow0 + srow) * o_sy + 2 * (px0 + spair);
+#if WR_ITXP == 64 && !defined(WR_INV_LDS_STORE)
+        // 64-pair tiles: a quad of lanes IS the four rows of one lane column (lane = 4 * column + row), and lane 4 c + p of the
+        // row-wise store wants pair 4 c + p of every row: a 4 x 4 transpose of {ev, od} pairs inside the quad -- two DPP
+        // exchanges (the lane one over, then the lane two over), no LDS.  (Through the wave's LDS rows, as the 32-pair tiles
+        // still do it, the write-back is two-way bank-conflicted by construction: it was all that was left of the kernel's
+        // conflict cycles, 1.6e8 per level-0 launch, profiles/r04/y_sq_*; -DWR_INV_LDS_STORE rebuilds that form.)
+        {
+            const bool b0 = lane & 1, b1 = lane & 2;
+            quad_exchange<0xB1>(b0, ev[0], ev[1]); quad_exchange<0xB1>(b0, od[0], od[1]);
+            quad_exchange<0xB1>(b0, ev[2], ev[3]); quad_exchange<0xB1>(b0, od[2], od[3]);
+            quad_exchange<0x4E>(b1, ev[0], ev[2]); quad_exchange<0x4E>(b1, od[0], od[2]);
+            quad_exchange<0x4E>(b1, ev[1], ev[3]); quad_exchange<0x4E>(b1, od[1], od[3]);
+        }
+        static_assert(WR_ITXP != 64 || (RW == 4 && RPS == 1), "a quad of lanes holds the four rows of a lane column");
+#pragma unroll
+        for (int st = 0; st < RW / RPS; st++)
+            if (own && yrow0 + st < n2) *reinterpret_cast<double2*>(dstp + (size_t)st * o_sy) = make_double2(ev[st & 3], od[st & 3]);
+#else
+        // through the wave's rows (everything has been read: LDS runs a wave's instructions in order)
+        double* o = ybw + yrow_off(r) + 2 * i;
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<double2*>(o + 2 * k) = make_double2(ev[k], od[k]);
 #pragma unroll
         for (int st = 0; st < RW / RPS; st++) {
             const int rr = st * RPS + srow;
             const double2 v = *reinterpret_cast<const double2*>(ybw + yrow_off(rr) + 2 * spair);
             if (own && yrow0 + rr < n2) *reinterpret_cast<double2*>(dstp + (size_t)(st * RPS) * o_sy) = v;
         }
+#endif
     };
     // y pass of one coefficient column cid of the z-plane in zbuf (scaled by the z step): the wave's four output rows,
     // scaled for the x pass
