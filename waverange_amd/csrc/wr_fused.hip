@@ -434,6 +434,12 @@ namespace {
 #ifndef WR_ITXP
 #define WR_ITXP 64
 #endif
+// DIAGNOSTIC (results are NOT a transform): leaves out one class of the inverse kernel's LDS instructions, to attribute the
+// SQ_LDS_* counters.  1: the y stage's pass over columns 64..127, 2: its leftover columns, 4: the x stage's reads, 8: the z
+// step's writes, 16: the y stage's writes, 32: the y stage's pass over columns 0..63.
+#ifndef WR_INV_DIAG_SKIP
+#define WR_INV_DIAG_SKIP 0
+#endif
 #ifndef WR_YPW
 #define WR_YPW 2
 #endif
@@ -449,7 +455,7 @@ static_assert(YPW % 2 == 0 && ITYP % YPW == 0 && ITXP % 4 == 0 && RW * XCG == 64
 constexpr int HX = ITXP + 4;             // coefficient columns per quadrant row (68)
 constexpr int HY = ITYP + 4;             // coefficient rows per quadrant (20)
 constexpr int CROW = HX / 2;             // 16-byte chunks per row (34)
-constexpr int NCI = 4 * HY * CROW;       // chunks per plane (2720)
+[[maybe_unused]] constexpr int NCI = 4 * HY * CROW;       // chunks per plane without padding (2720)
 // A thread's chunk slots: the first KH cover the y-low quadrants (LL, HL), the last KH the y-high ones (LH, HH), so
 // that the scale a slot's values leave the z step with is a compile-time constant
 constexpr int NCH = 2 * HY * CROW;       // chunks per y-half (1360)
@@ -475,7 +481,26 @@ constexpr int YPITCH = 88;
 constexpr int YWAVE = 8 * YPITCH;        // (7 x 88 + 10 + 72 = 698 doubles used)
 __device__ inline int yrow_off(int r) { return r * YPITCH + (r & 1) * 10; }
 #endif
-constexpr size_t LDS_INV = (size_t)2 * NCI * 16 + (size_t)INWAVE * YWAVE * 8;
+// The z buffer's strides, padded for the y stage's column reads (8 bytes per lane, consecutive columns; served 16 or 32 lanes
+// at a time by the compiler's choice of ds_read2_b64 / ds_read_b64, a lane's bank = its double's index mod 16 resp. 32):
+//  * the pass over columns 64..127 holds the last four x-low columns and the first sixty x-high ones: conflict-free when the
+//    quadrants lie 4 doubles apart mod 32 (unpadded: 1360 = 16 mod 32, lanes 0-3 against 20-23; mod 16: against 4-7);
+//  * the leftover pass holds the same eight columns of the even and of the odd plane: conflict-free when the planes lie 8
+//    doubles apart mod 16 (unpadded: 0).
+// Both cost one extra LDS cycle on every one of the pass's eleven reads: 33 cycles per wave and z-pair, 40 % of what was
+// left of the kernel's bank-conflict cycles (profiles/r05/s_lds_conflicts_by_instruction_class.txt).  A quadrant begins on
+// a multiple of eight chunks, so the z step's ds_write_b128 (eight consecutive lanes, eight consecutive chunks) never straddles one.
+#if WR_ITXP == 64
+constexpr int QPAD = 20;                 // doubles between two quadrants of a plane
+constexpr int PPAD = 8;                  // doubles between the two planes of a step
+#else
+constexpr int QPAD = 0, PPAD = 0;
+#endif
+constexpr int QS = HY * HX + QPAD;       // quadrant stride, doubles
+constexpr int PSC = (4 * QS + PPAD) / 2; // plane stride, 16-byte chunks
+static_assert(QPAD % 2 == 0 && PPAD % 2 == 0 && (HY * CROW) % 8 == 0, "chunks stay 16-byte aligned; quadrants begin on a multiple of eight chunks");
+static_assert(WR_ITXP != 64 || (QS % 32 == 4 && (2 * PSC) % 16 == 8), "strides of the z buffer against the y stage's reads");
+constexpr size_t LDS_INV = (size_t)2 * PSC * 16 + (size_t)INWAVE * YWAVE * 8;
 
 // A double of another lane of the quad (lanes 4q .. 4q + 3), by DPP: `v_mov_b32 ... quad_perm:[..]` on either half.
 // 0xB1 = quad_perm:[1,0,3,2] (the lane one over), 0x4E = quad_perm:[2,3,0,1] (the lane two over).
@@ -562,8 +587,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     s_sy = WR_INV_MEMPITCH; s_sz = (size_t)WR_INV_MEMPITCH * n2;
 #endif
     extern __shared__ double2 lds2[];
-    double2* zb = lds2;                   // [2][NCI]   the two z-reconstructed planes of a step
-    double* yb = reinterpret_cast<double*>(lds2 + 2 * NCI);  // [INWAVE][YWAVE] wave-private rows
+    double2* zb = lds2;                   // [2][PSC]   the two z-reconstructed planes of a step: four quadrants, QS doubles apart
+    double* yb = reinterpret_cast<double*>(lds2 + 2 * PSC);  // [INWAVE][YWAVE] wave-private rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m1 = n1 >> 1, m2 = n2 >> 1, m3 = n3 >> 1;
     const int tiles_x = (m1 + ITXP - 1) / ITXP;
@@ -586,8 +611,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         // all rows first -- a wave's load = two whole rows = eight whole lines -- and the two halo chunks of every row
         // afterwards was measured 5 % SLOWER, profiles/r05/c_ab_inverse_aligned_loads_same_box.txt.)
         const int c = half * NCH + (ch < NCH ? ch : 0);
-        zi[k] = c;
         const int q = c / (HY * CROW), rem = c - q * (HY * CROW);
+        zi[k] = c + q * (QPAD / 2);
         const int row = rem / CROW, cc = rem - row * CROW;
         const int gyp = (q & 2) ? mirror_d(py0 - 2 + row, m2) : mirror_s(py0 - 2 + row, m2);
         int gxp = px0 - 2 + 2 * cc;
@@ -655,12 +680,21 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         // local column of pair k is k + 2:  s[i-1..i+5] -> i+1..i+7,  d[i-2..i+5] -> i..i+7
         const double2* ps = reinterpret_cast<const double2*>(row + i);
         const double2* pd = reinterpret_cast<const double2*>(row + HX + i);
-        const double2 s0 = ps[0], s1 = ps[1], s2 = ps[2], s3 = ps[3];
-        const double2 d0 = pd[0], d1 = pd[1], d2 = pd[2], d3 = pd[3];
+        double2 s0, s1, s2, s3, d0, d1, d2, d3;
+        if (!(WR_INV_DIAG_SKIP & 4)) {
+            s0 = ps[0]; s1 = ps[1]; s2 = ps[2]; s3 = ps[3]; d0 = pd[0]; d1 = pd[1]; d2 = pd[2]; d3 = pd[3];
+        }
+        else s0 = s1 = s2 = s3 = d0 = d1 = d2 = d3 = make_double2((double)lane, (double)zplane);
         const double sv[7] = {s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y};
         const double dv[8] = {d0.x, d0.y, d1.x, d1.y, d2.x, d2.y, d3.x, d3.y};
         double ev[4], od[4];
         lift_inv_four(sv, dv, ev, od);
+        // s0.x is no operand of the lifting, and without a use the compiler narrows the four 16-byte reads of the s side to
+        // ds_read2_b64 / ds_read_b64 of the seven doubles it needs -- which are served 16 / 32 consecutive lanes at a time on
+        // 32 / 64 banks, where the rows' offsets (worked out for ds_read_b128's lane groups) put rows 0 and 1, 2 and 3 on the
+        // same banks: 26 extra LDS cycles per plane, 60 % of what was left of the kernel's conflict cycles
+        // (profiles/r05/s_lds_conflicts_by_instruction_class.txt).  The use sits behind the lifting so that nothing waits for it.
+        asm volatile("" :: "v"(s0.x));
         // The lane's eight results are 64 consecutive bytes of its row: stored as they are, every store instruction would
         // write 16 bytes out of every 64.  They leave row by row instead, one x-pair per lane: 1 KB of consecutive bytes per
         // instruction.
@@ -704,8 +738,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
     auto ycolumn = [&](const double2* zbuf, int cid, int J, double (&o)[4]) {  // J: first of the two local y-pairs rebuilt
         const int xh = cid >= HX;             // 0: x-low column, 1: x-high column
         const int col = cid - xh * HX;
-        const double* zl = reinterpret_cast<const double*>(zbuf) + (size_t)(xh) * (HY * HX) + col;        // y-low quadrant
-        const double* zh = reinterpret_cast<const double*>(zbuf) + (size_t)(2 + xh) * (HY * HX) + col;    // y-high quadrant
+        const double* zl = reinterpret_cast<const double*>(zbuf) + (size_t)(xh) * QS + col;        // y-low quadrant
+        const double* zh = reinterpret_cast<const double*>(zbuf) + (size_t)(2 + xh) * QS + col;    // y-high quadrant
         // local row of y-pair k is k + 2:  s[J-1..J+3] -> rows J+1..J+5,  d[J-2..J+3] -> rows J..J+5
         const double sr[5] = {zl[(J + 1) * HX], zl[(J + 2) * HX], zl[(J + 3) * HX], zl[(J + 4) * HX], zl[(J + 5) * HX]};
         const double dr[6] = {zh[(J + 0) * HX], zh[(J + 1) * HX], zh[(J + 2) * HX], zh[(J + 3) * HX], zh[(J + 4) * HX],
@@ -727,13 +761,15 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         for (int g = 0; g < YG; g++) {
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                double o[4];
-                ycolumn(zbuf, lane + 64 * p, J + 2 * g, o);
+                double o[4] = {1.0, 2.0, 3.0, 4.0};
+                if (!((WR_INV_DIAG_SKIP & 1) && p == 1) && !((WR_INV_DIAG_SKIP & 32) && p == 0)) ycolumn(zbuf, lane + 64 * p, J + 2 * g, o);
+                if (!(WR_INV_DIAG_SKIP & 16)) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) ybw[yrow_off(4 * g + r) + lane + 64 * p] = o[r];
+                    for (int r = 0; r < 4; r++) ybw[yrow_off(4 * g + r) + lane + 64 * p] = o[r];
+                } else asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
             }
         }
-        if (mine) {
+        if (mine && !(WR_INV_DIAG_SKIP & 2)) {
 #pragma unroll
             for (int r = 0; r < 4; r++) ybw[yrow_off(4 * tail_g + r) + 64 * NP + (lane & (YT - 1))] = tail[r];
         }
@@ -811,7 +847,8 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
                     od[e] = (d1prev[k][e] - WR_ALPHA * ((last2 ? s2prev[k][e] : S2) + s2prev[k][e])) * sc;
                     dprev[k][e] = d0; s1prev[k][e] = S1; d1prev[k][e] = D1; s2prev[k][e] = S2;
                 }
-                if (emit) { zb[zi[k]] = make_double2(ev[0], ev[1]); zb[NCI + zi[k]] = make_double2(od[0], od[1]); }
+                if (emit && !(WR_INV_DIAG_SKIP & 8)) { zb[zi[k]] = make_double2(ev[0], ev[1]); zb[PSC + zi[k]] = make_double2(od[0], od[1]); }
+                else if (WR_INV_DIAG_SKIP & 8) asm volatile("" :: "v"(ev[0]), "v"(ev[1]), "v"(od[0]), "v"(od[1]));
             }
         }
         STAMP(2);
@@ -821,9 +858,9 @@ __global__ __launch_bounds__(INTHR, 2) void k_inv_fused(
         STAMP(6);
         if (emit) {
             double tail[4] = {0.0, 0.0, 0.0, 0.0};
-            if (lane < 2 * YG * YT) ycolumn(zb + (tail_plane ? NCI : 0), 64 * NP + (lane & (YT - 1)), J + 2 * tail_g, tail);
+            if (lane < 2 * YG * YT && !(WR_INV_DIAG_SKIP & 2)) ycolumn(zb + (tail_plane ? PSC : 0), 64 * NP + (lane & (YT - 1)), J + 2 * tail_g, tail);
             yxstage(2 * j, zb, tail, lane < YG * YT);
-            yxstage(2 * j + 1, zb + NCI, tail, lane >= YG * YT && lane < 2 * YG * YT);
+            yxstage(2 * j + 1, zb + PSC, tail, lane >= YG * YT && lane < 2 * YG * YT);
             STAMP(4);
         }
     }
