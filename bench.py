@@ -919,7 +919,23 @@ def main():
         except OSError:
             pass
         return None
+    def worker_cpu_s():  # CPU seconds of the coder pool's workers so far (threads named wr-coder-<id>, wr_rangecoder.cpp)
+        tick, tot = os.sysconf("SC_CLK_TCK"), 0.0
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    with open("/proc/self/task/%s/stat" % tid) as fh:
+                        st = fh.read()
+                except OSError:
+                    continue
+                name, rest = st[st.index("(") + 1:st.rindex(")")], st[st.rindex(")") + 2:].split()
+                if name.startswith("wr-coder-"):
+                    tot += (int(rest[11]) + int(rest[12])) / tick  # utime + stime
+        except OSError:
+            return None
+        return tot
     thr0 = throttled_s()
+    wcpu0 = worker_cpu_s()
     cpu0 = sum(os.times()[:2])
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
     burn0 = api.stat(api.STAT_CLOCK_WARMUP_MS)
@@ -953,6 +969,8 @@ def main():
         stop_sampling.set()
         sampler.join()
     cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
+    wcpu1 = worker_cpu_s()
+    workers_cpu = None if wcpu0 is None or wcpu1 is None else (wcpu1 - wcpu0) / dt  # ... of them the coder pool's workers
     pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
     nfields = max(1, args.steps * batch)
     queue_wait = (api.stat(api.STAT_POOL_QUEUE_MS) - queue0) * 1e-3 / nfields   # per field: its planes' waits for a pool worker, summed
@@ -1120,6 +1138,9 @@ def main():
             pass
         out["hbm_planes_gib"] = round(api.stat(api.STAT_DEVICE_PLANE_BYTES) / 2 ** 30, 1)  # device buffers of quantized planes (in use + idle)
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
+        if workers_cpu is not None:
+            # ... split into the coder pool's workers and everything else (the lanes' threads, the HIP / HSA runtime's threads, Python)
+            out["host_cpus_busy_by"] = {"pool_workers": round(workers_cpu, 2), "other_threads": round(cpu_used - workers_cpu, 2)}
         out["pool_loops"] = pool_loops
         out["waits_per_field_s"] = {"planes_in_the_pool_queue_summed": round(queue_wait, 2), "device_memory_for_planes": round(plane_wait, 2),
                                     "decode_admission_gate": round(gate_wait, 2)}
