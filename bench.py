@@ -940,6 +940,7 @@ def main():
     idle0 = api.stat(api.STAT_POOL_IDLE_MS)
     burn0 = api.stat(api.STAT_CLOCK_WARMUP_MS)
     gate0 = api.stat(api.STAT_DECODE_GATE_MS)
+    winwait0 = api.stat(api.STAT_WINDOW_WAIT_MS)
     queue0, pwait0 = api.stat(api.STAT_POOL_QUEUE_MS), api.stat(api.STAT_PLANE_WAIT_MS)
     loops0 = api.pool_loop_stats()
     sampler = stop_sampling = None
@@ -972,6 +973,7 @@ def main():
     wcpu1 = worker_cpu_s()
     workers_cpu = None if wcpu0 is None or wcpu1 is None else (wcpu1 - wcpu0) / dt  # ... of them the coder pool's workers
     pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
+    window_wait = (api.stat(api.STAT_WINDOW_WAIT_MS) - winwait0) * 1e-3 / dt  # workers blocked on a plane window's DMA copy, on average
     nfields = max(1, args.steps * batch)
     queue_wait = (api.stat(api.STAT_POOL_QUEUE_MS) - queue0) * 1e-3 / nfields   # per field: its planes' waits for a pool worker, summed
     plane_wait = (api.stat(api.STAT_PLANE_WAIT_MS) - pwait0) * 1e-3 / nfields   # per field: waits for device memory for its planes
@@ -1141,6 +1143,7 @@ def main():
         if workers_cpu is not None:
             # ... split into the coder pool's workers and everything else (the lanes' threads, the HIP / HSA runtime's threads, Python)
             out["host_cpus_busy_by"] = {"pool_workers": round(workers_cpu, 2), "other_threads": round(cpu_used - workers_cpu, 2)}
+        out["pool_workers_waiting_for_window_dma"] = round(window_wait, 2)
         out["pool_loops"] = pool_loops
         out["waits_per_field_s"] = {"planes_in_the_pool_queue_summed": round(queue_wait, 2), "device_memory_for_planes": round(plane_wait, 2),
                                     "decode_admission_gate": round(gate_wait, 2)}

@@ -188,6 +188,8 @@ int wr_set_device_slots(int device, int nslots);
                                       call concerned fails) */
 #define WR_STAT_CLOCK_WARMUP_MS 8  /* milliseconds of clock warm-up load put in front of kernel stages (WR_CLOCK_WARMUP_MS, a measurement
                                       hook that is off by default: always 0 then) */
+#define WR_STAT_WINDOW_WAIT_MS 10  /* milliseconds host coders have waited inside their window requests for a window's DMA copy (a worker of the
+                                    * coder pool is blocked then, not idle), summed over coders */
 #define WR_STAT_DECODE_GATE_MS 9   /* milliseconds decode calls have waited for admission to the coder pool, holding no device memory yet
                                       (before: the same time in the pool's queues with their planes allocated), summed over calls */
 unsigned long wr_stat(int what);

@@ -184,6 +184,7 @@ def set_device_slots(device, nslots):
 
 STAT_EARLY_DECODES, STAT_SLOTS_POPULATED, STAT_DEVICE_PLANE_BYTES, STAT_POOL_IDLE_MS, STAT_POOL_STREAMS_MOVED = 0, 1, 2, 3, 4
 STAT_POOL_QUEUE_MS, STAT_PLANE_WAIT_MS, STAT_HANDOVER_ERRORS, STAT_CLOCK_WARMUP_MS, STAT_DECODE_GATE_MS = 5, 6, 7, 8, 9
+STAT_WINDOW_WAIT_MS = 10
 
 
 def stat(what):

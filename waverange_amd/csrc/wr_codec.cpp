@@ -412,9 +412,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
             // ---- stage "up": the field goes host -> device; the kernel stage is only claimed once it has
             // arrived, so other calls compute meanwhile
             d_fld = slot->field;
-            const Piece pc = {d_fld, fld.host, n * sizeof(double)};
-            if ((rc = xfer_start(c, &c->x_field, &pc, 1, kUp)) != WR_OK) return rc;
-            if ((rc = xfer_wait(&c->x_field)) != WR_OK) return rc;
+            if ((rc = xfer_field(c, &c->x_field, d_fld, fld.host, n * sizeof(double), kUp)) != WR_OK) return rc;
             local.h2d_ms = (float)c->x_field.ms;
         }
         double* resid = d_fld;
@@ -491,8 +489,7 @@ int encode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, int wtflag, con
         }
         // ---- stage "down": the histograms were sent off as the planes completed; the residual follows them
         if (rc == WR_OK && c->keep_residual && info->nlay && fld.host) {
-            const Piece pc = {fld.host, resid, n * sizeof(double)};
-            if ((rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) == WR_OK) rc = xfer_wait(&c->x_field);
+            rc = xfer_field(c, &c->x_field, fld.host, resid, n * sizeof(double), kDown);
         }
         // The slot's histogram buffer must not be reused before its downloads are done (the coder threads wait
         // for the same transfers; xfer_wait is safe to call from both sides).  With the coder pool, every plane
@@ -752,9 +749,7 @@ int decode_impl(wr_ctx* c, FieldRef fld, int nx, int ny, int nz, const wr_enc_in
         if (rc) return rc;
         if (fld.host) {
             // ---- stage "down": the reconstructed field, device -> host
-            const Piece pc = {fld.host, d_fld, n * sizeof(double)};
-            if ((rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) != WR_OK) return rc;
-            if ((rc = xfer_wait(&c->x_field)) != WR_OK) return rc;
+            if ((rc = xfer_field(c, &c->x_field, fld.host, d_fld, n * sizeof(double), kDown)) != WR_OK) return rc;
             local.d2h_ms = (float)c->x_field.ms;
         }
     } catch (const std::exception& e) {
@@ -851,9 +846,7 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
     if (int rc = slot.acquire(c, need)) return rc;
     DevPool* const pool = c->pool;
     {
-        const Piece pc = {slot->field, h_fld, n * sizeof(double)};
-        if (int rc = xfer_start(c, &c->x_field, &pc, 1, kUp)) return rc;
-        if (int rc = xfer_wait(&c->x_field)) return rc;
+        if (int rc = xfer_field(c, &c->x_field, slot->field, h_fld, n * sizeof(double), kUp)) return rc;
     }
     double* res = nullptr;
     {
@@ -862,9 +855,7 @@ int wr_transform_host(wr_ctx* c, double* h_fld, int nx, int ny, int nz, int lvl)
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    const Piece pc = {h_fld, res, n * sizeof(double)};
-    if (int rc = xfer_start(c, &c->x_field, &pc, 1, kDown)) return rc;
-    return xfer_wait(&c->x_field);
+    return xfer_field(c, &c->x_field, h_fld, res, n * sizeof(double), kDown);
 }
 
 }  // extern "C"

@@ -321,6 +321,7 @@ struct Piece { void* dst; const void* src; size_t bytes; };
 // Starts the pieces of one transfer (SDMA engine for pinned memory, hipMemcpyAsync otherwise) / waits for it
 int xfer_start(wr_ctx* c, wr_ctx::Xfer* x, const Piece* pc, int count, Dir dir);
 int xfer_wait(wr_ctx::Xfer* x);
+int xfer_field(wr_ctx* c, wr_ctx::Xfer* x, void* dst, const void* src, size_t bytes, Dir dir);  // a whole field, in pieces (blocks until done)
 
 using PlaneStream = wr_ctx::PlaneStream;
 void plane_release(wr_ctx* c, int l);

@@ -327,6 +327,25 @@ int xfer_wait(wr_ctx::Xfer* x)
     return rc;
 }
 
+// A whole field host <-> device: in pieces of 128 MB, one in flight.  The DMA engine of a direction serves its queue in
+// order, so a field queued as one 8.6 GB copy (150 ms) holds up every 15 MB plane window queued behind it -- and a coder
+// whose next window is late blocks with all the streams of its session: 0.87 of the pool's 16 workers were blocked that way
+// on average (profiles/r05/u_*).  In pieces, a window waits for 2 ms of the field at most; the field pays a wake-up per
+// piece (~2 %).
+int xfer_field(wr_ctx* c, wr_ctx::Xfer* x, void* dst, const void* src, size_t bytes, Dir dir)
+{
+    constexpr size_t kFieldPiece = (size_t)128 << 20;
+    double ms = 0;
+    for (size_t off = 0; off < bytes; off += kFieldPiece) {
+        const Piece pc = {static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, bytes - off < kFieldPiece ? bytes - off : kFieldPiece};
+        if (int rc = xfer_start(c, x, &pc, 1, dir)) return rc;
+        if (int rc = xfer_wait(x)) return rc;
+        ms += x->ms;
+    }
+    x->ms = ms;
+    return WR_OK;
+}
+
 // ---- device-resident planes and their host windows -------------------------------------------------------------------
 // a window: 256 coder blocks, 15.36 MB, ~0.3 ms on a DMA engine (WR_WINDOW_BLOCKS: 1..256 blocks, for tests that want
 // many windows on small fields)
@@ -447,6 +466,22 @@ uint8_t* refused_window(PlaneStream* s, const char* who, const char* why, size_t
 
 }  // namespace
 
+namespace {
+// xfer_wait on behalf of a host coder inside its window request: what it waits is booked (WR_STAT_WINDOW_WAIT_MS)
+int window_xfer_wait(wr_ctx::Xfer* x)
+{
+    const double t0 = now();
+    const int rc = xfer_wait(x);
+    const double us = (now() - t0) * 1e6;
+    if (us >= 50.0) {  // microseconds, carried over so that many short waits add up
+        static std::atomic<unsigned long> carry_us{0};
+        const unsigned long tot = carry_us.fetch_add((unsigned long)us) + (unsigned long)us;
+        if (tot >= 1000) { carry_us -= (tot / 1000) * 1000; g_stat[WR_STAT_WINDOW_WAIT_MS] += tot / 1000; }
+    }
+    return rc;
+}
+}  // namespace
+
 // Encoder side: the symbols [first, first + count) of the plane, fetched into the ring; the following chunk is
 // started into the buffer the coder has just left, so that it arrives while this one is being coded.
 uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
@@ -467,7 +502,7 @@ uint8_t* plane_window_encode(void* user, size_t first, size_t* count)
         const int np = plane_pieces(s, first, want, s.buf[b], true, pc);
         if (xfer_start(c, &s.x[b], pc, np, kDown) != WR_OK) s.err = 1;
     }
-    if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;
+    if (window_xfer_wait(&s.x[b]) != WR_OK) s.err = 1;
     s.copy_ms += s.x[b].ms;
     s.cur = b;
     s.ahead = false;
@@ -514,7 +549,7 @@ uint8_t* plane_window_decode(void* user, size_t first, size_t* count)
         return nullptr;
     }
     const int b = s.cur ^ 1;
-    if (xfer_wait(&s.x[b]) != WR_OK) s.err = 1;  // the upload of two windows ago
+    if (window_xfer_wait(&s.x[b]) != WR_OK) s.err = 1;  // the upload of two windows ago
     s.copy_ms += s.x[b].ms; s.x[b].ms = 0;
     s.cur = b;
     s.win_first = first;
