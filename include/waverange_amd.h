@@ -193,6 +193,9 @@ int wr_set_device_slots(int device, int nslots);
 #define WR_STAT_DECODE_GATE_MS 9   /* milliseconds decode calls have waited for admission to the coder pool, holding no device memory yet
                                       (before: the same time in the pool's queues with their planes allocated), summed over calls */
 unsigned long wr_stat(int what);
+/* Hands the idle buffers of the device's plane pool back to the device (the pool keeps the plane memory of finished calls for
+ * the next ones: after a burst of concurrent calls that can be most of the HBM).  Buffers in use are not touched. */
+int wr_ctx_trim(wr_ctx *c);
 /* coder pool, per loop kind {scalar encoder, scalar decoder, 16-lane decoder for dominant-symbol planes, 16-lane encoder}
  * -- WR_POOL_LOOP_KINDS entries each: seconds the workers have spent in block steps of that loop and stream-blocks (60000
  * symbols) advanced: symbols per worker-second in the pipeline */

@@ -503,11 +503,21 @@ def test_host_api_error_paths(ctx, api):
     api.set_device_slots(0, 3)
     with pytest.raises(api.WaveRangeError, match="device index"):
         api.set_device_slots(1000, 2)
+    # a device allocation the GPU cannot serve: an error, and nothing of it is left behind as the thread's "last error" for the
+    # next call's launch check to trip over (round 5: a refused 8.6 GB allocation failed the encode that followed it)
+    with pytest.raises(api.WaveRangeError, match="hipMalloc"):
+        ctx.alloc(1 << 42)
     # and the context still works
     again, _ = ctx.encode_host(f, 1e-6)
     assert np.array_equal(again["data"], enc["data"])
     ctx.decode_host(out, enc)
     assert np.abs(out - f).max() <= 1.05e-6 * np.abs(f).max()
+    # the plane pool keeps the calls' plane memory for the next ones; wr_ctx_trim hands what is idle back to the device
+    assert api.stat(api.STAT_DEVICE_PLANE_BYTES) > 0
+    ctx.trim()
+    assert api.stat(api.STAT_DEVICE_PLANE_BYTES) == 0
+    again, _ = ctx.encode_host(f, 1e-6)
+    assert np.array_equal(again["data"], enc["data"])
 
 
 def test_caller_registered_buffers(ctx, api, oracle):

@@ -134,6 +134,8 @@ def lib():
     L.wr_range_decode.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t]
     L.wr_range_encode_multi.restype = None
     L.wr_range_encode_multi.argtypes = [C.c_int, _vp, C.c_size_t, _vp, _vp]
+    L.wr_ctx_trim.restype = C.c_int
+    L.wr_ctx_trim.argtypes = [C.c_void_p]
     L.wr_range_decode_multi.restype = None
     L.wr_range_decode_multi.argtypes = [C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]
     L.wr_range_encode_pool.argtypes = [C.c_int, _vp, _vp, _vp, _vp]
@@ -471,6 +473,10 @@ class Context:
 
     def sync(self):
         _check(lib().wr_ctx_sync(self.h))
+
+    def trim(self):
+        """idle buffers of the device's plane pool go back to the device (wr_ctx_trim)"""
+        _check(lib().wr_ctx_trim(self.h))
 
     def set_keep_residual(self, keep):
         lib().wr_ctx_set_keep_residual(self.h, int(keep))

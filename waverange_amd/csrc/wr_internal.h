@@ -53,8 +53,12 @@ double now();
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
+        if (e_ != hipSuccess) {                                                              \
+            /* the runtime keeps the error as the thread's "last error" until somebody asks for it: left there, it would fail   \
+               the NEXT call's check of a kernel launch (a refused 8.6 GB hipMalloc once failed a later encode that way) */   \
+            (void)hipGetLastError();                                                         \
             return ::wri::fail(WR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                    \
     } while (0)
 
 // One set of device work space.  A device phase owns a slot from its first copy to its last; the

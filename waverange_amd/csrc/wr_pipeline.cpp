@@ -791,6 +791,13 @@ void wr_set_encoder_threads(int nthreads) { g_enc_threads.store(nthreads < 0 ? 0
 void wr_set_writeback_residual(int on) { g_writeback.store(on ? 1 : 0); }
 void wr_pool_loop_stats(double* seconds, double* blocks) { wrrc::pool_loop_stats(seconds, blocks); }
 
+int wr_ctx_trim(wr_ctx* c)
+{
+    if (int rc = ctx_bind(c)) return rc;
+    c->pool->planes.drop_idle();
+    return WR_OK;
+}
+
 unsigned long wr_stat(int what)
 {
     if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
