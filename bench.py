@@ -970,6 +970,7 @@ def main():
         stop_sampling.set()
         sampler.join()
     cpu_used = (sum(os.times()[:2]) - cpu0) / dt  # this rank's average number of busy CPUs over the timed region
+    planes_bytes = api.stat(api.STAT_DEVICE_PLANE_BYTES)  # the plane pool after the timed region (in use + idle: it only grows during a run)
     wcpu1 = worker_cpu_s()
     workers_cpu = None if wcpu0 is None or wcpu1 is None else (wcpu1 - wcpu0) / dt  # ... of them the coder pool's workers
     pool_idle = (api.stat(api.STAT_POOL_IDLE_MS) - idle0) * 1e-3 / dt  # workers waiting for a job, on average
@@ -1139,7 +1140,7 @@ def main():
             out["host_peak_rss_gib"] = round(int(hwm[1]) / 2 ** 20, 2)
         except Exception:
             pass
-        out["hbm_planes_gib"] = round(api.stat(api.STAT_DEVICE_PLANE_BYTES) / 2 ** 30, 1)  # device buffers of quantized planes (in use + idle)
+        out["hbm_planes_gib"] = round(planes_bytes / 2 ** 30, 1)  # device buffers of quantized planes at the end of the timed region (in use + idle)
         out["host_cpus_busy"] = round(cpu_used, 2)  # process CPU time / wall time of the timed region (this rank)
         if workers_cpu is not None:
             # ... split into the coder pool's workers and everything else (the lanes' threads, the HIP / HSA runtime's threads, Python)
