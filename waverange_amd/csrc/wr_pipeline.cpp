@@ -467,17 +467,15 @@ uint8_t* refused_window(PlaneStream* s, const char* who, const char* why, size_t
 }  // namespace
 
 namespace {
-// xfer_wait on behalf of a host coder inside its window request: what it waits is booked (WR_STAT_WINDOW_WAIT_MS)
+// xfer_wait on behalf of a host coder inside its window request: what it waits is booked (WR_STAT_WINDOW_WAIT_MS; kept in
+// microseconds, so that many short waits add up)
+std::atomic<unsigned long long> g_window_wait_us{0};
 int window_xfer_wait(wr_ctx::Xfer* x)
 {
     const double t0 = now();
     const int rc = xfer_wait(x);
     const double us = (now() - t0) * 1e6;
-    if (us >= 50.0) {  // microseconds, carried over so that many short waits add up
-        static std::atomic<unsigned long> carry_us{0};
-        const unsigned long tot = carry_us.fetch_add((unsigned long)us) + (unsigned long)us;
-        if (tot >= 1000) { carry_us -= (tot / 1000) * 1000; g_stat[WR_STAT_WINDOW_WAIT_MS] += tot / 1000; }
-    }
+    if (us >= 20.0) g_window_wait_us += (unsigned long long)us;
     return rc;
 }
 }  // namespace
@@ -803,6 +801,7 @@ unsigned long wr_stat(int what)
     if (what == WR_STAT_POOL_IDLE_MS) return (unsigned long)(wrrc::pool_idle_seconds() * 1e3);
     if (what == WR_STAT_POOL_STREAMS_MOVED) return wrrc::pool_streams_moved();
     if (what == WR_STAT_POOL_QUEUE_MS) return (unsigned long)(wrrc::pool_queue_seconds() * 1e3);
+    if (what == WR_STAT_WINDOW_WAIT_MS) return (unsigned long)(g_window_wait_us.load() / 1000);
     return (what >= 0 && what < 12) ? g_stat[what].load() : 0;
 }
 void wr_set_coder_pool(int nthreads, int decoder_streams)
