@@ -375,22 +375,27 @@ def fit_jobs(want, ntols, field_bytes, hbm_free, pinned_share=None, host_mode=Tr
     # field and the pool of output fields (two-phase decode) are a fixed 1 + out_pool field sizes in host-to-host mode.
     # HBM per field in flight: the planes of its encoder and decoder contexts (up to 4 + 4 at the bench's tolerances =
     # one field size) next to three work-space slots of 2.2 field sizes; resident mode: two field buffers per lane more
+    # (beyond four planes per field -- `--tols 1e-16`: eight, six of them at a byte per symbol -- a field's coded streams are most
+    # of a field size and every lane holds them twice, in the encoder's output and in a hand-over buffer: two field sizes per lane;
+    # sized at 0.6 such a run took more than the 270 GiB a box allows and was killed, profiles/r05/NOTES.md)
+    # (what handing consumed pages back saves there has not been measured: no discount for it)
+    lane_ample, lane_tight = (0.6, 0.25) if planes_per_field <= 4 else (0.25 * planes_per_field, 0.25 * planes_per_field)
     regime, trim, by_mem, budget = "ample", False, want, None
     if mem:
         budget = 0.8 * mem / mem_share
         fixed = (1 + out_pool) * field_bytes if host_mode else 0
-        by_mem = int((budget - fixed) // (0.6 * field_bytes * ntols))
+        by_mem = int((budget - fixed) // (lane_ample * field_bytes * ntols))
         if by_mem < min(want, by_cpu):
             # consumed coded streams hand their pages back to the system (drop_pages): ~0.25 field sizes per lane instead of
             # 0.6, at ~3 % of the rate (the pages are faulted in and zeroed again for every field)
             regime, trim = "tight", True
-            by_mem = int((budget - fixed) // (0.25 * field_bytes * ntols))
+            by_mem = int((budget - fixed) // (lane_tight * field_bytes * ntols))
             if by_mem < 1 and host_mode and out_pool > 1:
                 out_pool = 1
                 fixed = 2 * field_bytes
-                by_mem = int((budget - fixed) // (0.25 * field_bytes * ntols))
+                by_mem = int((budget - fixed) // (lane_tight * field_bytes * ntols))
             if by_mem < 1:
-                need = fixed + 0.25 * field_bytes * ntols
+                need = fixed + lane_tight * field_bytes * ntols
                 raise SizingRefused(
                     "bench.py: this rank's share of the host memory cannot hold the workload: %.1f GiB available / %d ranks on the node x 0.8 = %.1f GiB, "
                     "but the smallest configuration -- input field + one output field (2 x %.1f GiB) + one lane per tolerance (%d x 0.25 x %.1f GiB of "

@@ -72,6 +72,10 @@ def test_bench_batch_sizing():
     # two slots leave room for more lanes; tol 1e-16 (8 planes per field) for half as many
     assert bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, nslots=2, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 2 * 2.2 * fb) // (0.6 * fb * 2))
     assert bench.fit_jobs(64, 1, fb, 288 * 10 ** 9, planes_per_field=8, host_mem=big)[1]["jobs_by_hbm"] == int((0.92 * 288e9 - 3 * 2.2 * fb) // (1.2 * fb))
+    # ... and host memory for two field sizes per lane (coded streams of most of a field size, held twice): on a box that allows
+    # 270 GiB, 11 lanes -- sized like a 4-plane run (0.6) it took more than that and the box killed it (round 5)
+    jobs, lim = bench.fit_jobs(20, 1, fb, 288 * 10 ** 9, planes_per_field=8, pooled=True, host_mem=270 * 2 ** 30, cpus=16)
+    assert lim["jobs_by_host_mem"] == int((0.8 * 270 * 2 ** 30 - 5 * fb) // (2.0 * fb)) == 11 and jobs == 11
     # with the coder pool a lane is not a thread: two and a half fields in flight per CPU (--fields-per-cpu)
     jobs, lim = bench.fit_jobs(64, 2, fb, 288 * 10 ** 9, pooled=True, host_mem=big)
     assert lim["jobs_by_cpu"] == max(1, int(2.5 * lim["cpus_per_rank"] // 2))
