@@ -1716,7 +1716,11 @@ private:
     {
         if (steal_idle_test_ > 0) return steal_idle_test_;
         const int w = (int)workers_.size();
-        return w < 4 ? 1 : (w + 3) / 4;
+        // (an eighth of the workers: two of 16.  A quarter until the end of round 5 -- from when the workers stopped blocking on
+        // window copies, idle workers are idle for want of streams, and two of them taking over half a session pay:
+        // 16.90 / 17.00 -> 17.54 / 17.61 GB/s same box, 1.05 -> 0.63-0.9 workers idle; one idle worker: 17.62 / 17.37:
+        // profiles/r05/z_ab_steal_threshold_k10_same_box.txt)
+        return w < 4 ? 1 : (w + 7) / 8;
     }
     std::atomic<unsigned long> moved_{0};
 
@@ -1755,7 +1759,7 @@ private:
     {
         std::lock_guard<std::mutex> lk(mu_);
         lanes_[(size_t)id] = g.count();
-        // Only when a good part of the pool has nothing to do (a quarter of the workers): a
+        // Only when part of the pool has nothing to do (steal_idle_min: an eighth of the workers): a
         // lone caller, a short batch, the drain of a run.  In steady state with every worker busy most of the time, a
         // worker that is idle for a moment would split a well-filled session into two half-filled ones, and a 16-lane
         // loop at 8 lanes does 70 % of the work per second: measured 10.7 GB/s against 11.8 without (profiles/r03).
